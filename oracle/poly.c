@@ -1,0 +1,167 @@
+/* oracle/poly.c -- see poly.h.  TEST INFRASTRUCTURE ONLY. */
+#include "poly.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* fft_classic: bit-reverse the input, then radix-2 DIT butterflies with the
+ * forward root w = primitive_root_of_unity(lg): out[k] = sum_j a[j] w^(jk). */
+static void ntt_root(gl_t *a, unsigned lg, gl_t root) {
+  size_t n = (size_t)1 << lg;
+  for (size_t i = 0; i < n; i++) {
+    size_t j = bitrev(i, lg);
+    if (i < j) {
+      gl_t t = a[i];
+      a[i] = a[j];
+      a[j] = t;
+    }
+  }
+  /* twiddle table w^i, i < n/2 */
+  gl_t *tw = (gl_t *)malloc(sizeof(gl_t) * (n / 2 + 1));
+  tw[0] = 1;
+  for (size_t i = 1; i < n / 2; i++) tw[i] = gl_mul(tw[i - 1], root);
+  for (unsigned s = 1; s <= lg; s++) {
+    size_t m = (size_t)1 << s, half = m >> 1, stride = n / m;
+    for (size_t k = 0; k < n; k += m) {
+      for (size_t j = 0; j < half; j++) {
+        gl_t u = a[k + j];
+        gl_t v = gl_mul(a[k + j + half], tw[j * stride]);
+        a[k + j] = gl_add(u, v);
+        a[k + j + half] = gl_sub(u, v);
+      }
+    }
+  }
+  free(tw);
+}
+void ntt(gl_t *a, unsigned lg) {
+  if (lg == 0) return;
+  ntt_root(a, lg, gl_root_of_unity(lg));
+}
+void intt(gl_t *a, unsigned lg) {
+  size_t n = (size_t)1 << lg;
+  if (lg) ntt_root(a, lg, gl_inv(gl_root_of_unity(lg)));
+  gl_t ninv = gl_inv((gl_t)n);
+  for (size_t i = 0; i < n; i++) a[i] = gl_mul(a[i], ninv);
+}
+void coset_ntt(gl_t *a, unsigned lg, gl_t shift) {
+  size_t n = (size_t)1 << lg;
+  gl_t p = 1;
+  for (size_t i = 0; i < n; i++) {
+    a[i] = gl_mul(a[i], p);
+    p = gl_mul(p, shift);
+  }
+  ntt(a, lg);
+}
+void coset_intt(gl_t *a, unsigned lg, gl_t shift) {
+  size_t n = (size_t)1 << lg;
+  intt(a, lg);
+  gl_t si = gl_inv(shift), p = 1;
+  for (size_t i = 0; i < n; i++) {
+    a[i] = gl_mul(a[i], p);
+    p = gl_mul(p, si);
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+static unsigned log2sz(size_t n) {
+  unsigned l = 0;
+  while (((size_t)1 << l) < n) l++;
+  return l;
+}
+
+void merkle_build(merkle_t *t, const gl_t *leaves, size_t n_leaves, size_t leaf_len, unsigned cap_h) {
+  unsigned lg = log2sz(n_leaves);
+  t->n_leaves = n_leaves;
+  t->cap_h = cap_h;
+  t->leaf_len = leaf_len;
+  t->n_levels = lg - cap_h + 1;
+  t->levels = (digest_t **)malloc(sizeof(digest_t *) * t->n_levels);
+  t->levels[0] = (digest_t *)malloc(sizeof(digest_t) * n_leaves);
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n_leaves; i++) t->levels[0][i] = kh_hash_or_noop(leaves + i * leaf_len, leaf_len);
+  for (unsigned l = 1; l < t->n_levels; l++) {
+    size_t cnt = n_leaves >> l;
+    t->levels[l] = (digest_t *)malloc(sizeof(digest_t) * cnt);
+    const digest_t *prev = t->levels[l - 1];
+    digest_t *cur = t->levels[l];
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < cnt; i++) cur[i] = kh_two_to_one(&prev[2 * i], &prev[2 * i + 1]);
+  }
+  t->cap = t->levels[t->n_levels - 1];
+}
+void merkle_free(merkle_t *t) {
+  if (!t->levels) return;
+  for (unsigned l = 0; l < t->n_levels; l++) free(t->levels[l]);
+  free(t->levels);
+  t->levels = NULL;
+}
+unsigned merkle_prove(const merkle_t *t, size_t idx, digest_t *siblings) {
+  unsigned cnt = t->n_levels - 1;
+  for (unsigned l = 0; l < cnt; l++) {
+    siblings[l] = t->levels[l][idx ^ 1];
+    idx >>= 1;
+  }
+  return cnt;
+}
+int merkle_verify(const gl_t *leaf, size_t leaf_len, size_t idx, const digest_t *cap, unsigned cap_h,
+                  const digest_t *siblings, unsigned n_sib) {
+  digest_t cur = kh_hash_or_noop(leaf, leaf_len);
+  for (unsigned l = 0; l < n_sib; l++) {
+    cur = (idx & 1) ? kh_two_to_one(&siblings[l], &cur) : kh_two_to_one(&cur, &siblings[l]);
+    idx >>= 1;
+  }
+  if (idx >= ((size_t)1 << cap_h)) return 0;
+  return memcmp(cur.b, cap[idx].b, DIGEST_BYTES) == 0;
+}
+
+/* ------------------------------------------------------------------------ */
+static void batch_commit(batch_t *b, unsigned cap_h) {
+  size_t n = (size_t)1 << b->d, N = n << b->rate_bits, nc = b->ncols;
+  unsigned lgN = b->d + b->rate_bits;
+  b->leaves = (gl_t *)malloc(sizeof(gl_t) * N * nc);
+#pragma omp parallel
+  {
+    gl_t *tmp = (gl_t *)malloc(sizeof(gl_t) * N);
+#pragma omp for schedule(dynamic, 1)
+    for (size_t c = 0; c < nc; c++) {
+      /* lde: zero-pad to N, coset_fft with shift = MULTIPLICATIVE_GROUP_GENERATOR */
+      memcpy(tmp, b->coeffs + c * n, sizeof(gl_t) * n);
+      memset(tmp + n, 0, sizeof(gl_t) * (N - n));
+      coset_ntt(tmp, lgN, GL_GENERATOR);
+      /* transpose + reverse_index_bits_in_place */
+      for (size_t i = 0; i < N; i++) b->leaves[bitrev(i, lgN) * nc + c] = tmp[i];
+    }
+    free(tmp);
+  }
+  merkle_build(&b->tree, b->leaves, N, nc, cap_h);
+}
+void batch_from_values(batch_t *b, const gl_t *vals, size_t ncols, unsigned d, unsigned rate_bits, unsigned cap_h) {
+  size_t n = (size_t)1 << d;
+  b->ncols = ncols;
+  b->d = d;
+  b->rate_bits = rate_bits;
+  b->coeffs = (gl_t *)malloc(sizeof(gl_t) * n * ncols);
+  memcpy(b->coeffs, vals, sizeof(gl_t) * n * ncols);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (size_t c = 0; c < ncols; c++) intt(b->coeffs + c * n, d);
+  batch_commit(b, cap_h);
+}
+void batch_from_coeffs(batch_t *b, const gl_t *coeffs, size_t ncols, unsigned d, unsigned rate_bits, unsigned cap_h) {
+  size_t n = (size_t)1 << d;
+  b->ncols = ncols;
+  b->d = d;
+  b->rate_bits = rate_bits;
+  b->coeffs = (gl_t *)malloc(sizeof(gl_t) * n * ncols);
+  memcpy(b->coeffs, coeffs, sizeof(gl_t) * n * ncols);
+  batch_commit(b, cap_h);
+}
+void batch_free(batch_t *b) {
+  free(b->coeffs);
+  free(b->leaves);
+  merkle_free(&b->tree);
+  b->coeffs = b->leaves = NULL;
+}
+ext_t poly_eval_ext(const gl_t *coeffs, size_t n, ext_t x) {
+  ext_t acc = ext_from(0);
+  for (size_t i = n; i-- > 0;) acc = ext_add(ext_mul(acc, x), ext_from(coeffs[i]));
+  return acc;
+}

@@ -1,0 +1,140 @@
+// gl.hpp -- Goldilocks field (p = 2^64 - 2^32 + 1) and its quadratic extension
+// F_p[X]/(X^2 - 7) for host and gfx950 device code.
+//
+// This is the arithmetic of plonky2_field 0.2.2 GoldilocksField /
+// QuadraticExtension (un-vendored dependency of the reference; in-tree anchors:
+// plonky2-backend/src/lib.rs:11-14, tests/test_assert_zero.rs:275-285).
+//
+// CDNA4 has no 64x64 multiplier: a product is built from v_mul_lo/hi_u32 /
+// v_mad_u64_u32 pieces by the compiler (__umul64hi), and the reduction uses only
+// shifts/adds because 2^64 = 2^32 - 1 and 2^96 = -1 (mod p).  No MFMA anywhere.
+// Values stored in memory are always canonical (< p).
+#pragma once
+#include <cstdint>
+#include <cstddef>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define P2_HD __host__ __device__ __forceinline__
+#else
+#define P2_HD inline
+#endif
+
+namespace p2 {
+
+typedef uint64_t gl_t;
+constexpr uint64_t GL_P = 0xFFFFFFFF00000001ULL;
+constexpr uint64_t GL_EPS = 0xFFFFFFFFULL;
+constexpr uint64_t GL_GEN = 7;  // multiplicative generator = coset shift
+constexpr uint64_t GL_ROOT_2_32 = 1753635133440165772ULL;  // 7^((p-1)/2^32)
+
+P2_HD gl_t gl_canon(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
+P2_HD gl_t gl_add(gl_t a, gl_t b) {
+  uint64_t s = a + b;
+  if (s < a || s >= GL_P) s -= GL_P;
+  return s;
+}
+P2_HD gl_t gl_sub(gl_t a, gl_t b) { return a >= b ? a - b : a - b + GL_P; }
+P2_HD gl_t gl_neg(gl_t a) { return a ? GL_P - a : 0; }
+P2_HD gl_t gl_dbl(gl_t a) { return gl_add(a, a); }
+
+// reduce hi:lo (a 128-bit value) mod p -> canonical
+P2_HD gl_t gl_reduce128(uint64_t lo, uint64_t hi) {
+  uint64_t hh = hi >> 32, hl = hi & GL_EPS;
+  uint64_t t0 = lo - hh;
+  if (lo < hh) t0 -= GL_EPS;
+  uint64_t t1 = hl * GL_EPS;  // (hl << 32) - hl
+  uint64_t t2 = t0 + t1;
+  if (t2 < t1) t2 += GL_EPS;
+  return gl_canon(t2);
+}
+P2_HD gl_t gl_mul(gl_t a, gl_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint64_t lo = a * b;
+  uint64_t hi = __umul64hi(a, b);
+#else
+  unsigned __int128 x = (unsigned __int128)a * b;
+  uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+#endif
+  return gl_reduce128(lo, hi);
+}
+P2_HD gl_t gl_sqr(gl_t a) { return gl_mul(a, a); }
+// multiply by a small constant (< 2^32): the product fits in 96 bits
+P2_HD gl_t gl_mul_small(gl_t a, uint32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint64_t lo = a * (uint64_t)k;
+  uint64_t hi = __umul64hi(a, (uint64_t)k);
+#else
+  unsigned __int128 x = (unsigned __int128)a * k;
+  uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+#endif
+  // hi < 2^32: only the hl term
+  uint64_t t1 = hi * GL_EPS;
+  uint64_t t2 = lo + t1;
+  if (t2 < t1) t2 += GL_EPS;
+  return gl_canon(t2);
+}
+P2_HD gl_t gl_pow(gl_t b, uint64_t e) {
+  gl_t r = 1;
+  while (e) {
+    if (e & 1) r = gl_mul(r, b);
+    b = gl_sqr(b);
+    e >>= 1;
+  }
+  return r;
+}
+P2_HD gl_t gl_inv(gl_t a) { return gl_pow(a, GL_P - 2); }
+// primitive 2^k-th root of unity
+P2_HD gl_t gl_root(unsigned k) {
+  gl_t g = GL_ROOT_2_32;
+  for (unsigned i = k; i < 32; i++) g = gl_sqr(g);
+  return g;
+}
+P2_HD uint32_t bitrev32(uint32_t x, unsigned bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return bits ? (__brev(x) >> (32 - bits)) : 0;
+#else
+  uint32_t r = 0;
+  for (unsigned i = 0; i < bits; i++) {
+    r = (r << 1) | (x & 1);
+    x >>= 1;
+  }
+  return r;
+#endif
+}
+
+struct ext_t {
+  gl_t c0, c1;
+};
+P2_HD ext_t ext_make(gl_t a, gl_t b) {
+  ext_t r;
+  r.c0 = a;
+  r.c1 = b;
+  return r;
+}
+P2_HD ext_t ext_from(gl_t a) { return ext_make(a, 0); }
+P2_HD ext_t ext_add(ext_t a, ext_t b) { return ext_make(gl_add(a.c0, b.c0), gl_add(a.c1, b.c1)); }
+P2_HD ext_t ext_sub(ext_t a, ext_t b) { return ext_make(gl_sub(a.c0, b.c0), gl_sub(a.c1, b.c1)); }
+P2_HD ext_t ext_mul(ext_t a, ext_t b) {
+  gl_t c0 = gl_add(gl_mul(a.c0, b.c0), gl_mul_small(gl_mul(a.c1, b.c1), 7));
+  gl_t c1 = gl_add(gl_mul(a.c0, b.c1), gl_mul(a.c1, b.c0));
+  return ext_make(c0, c1);
+}
+P2_HD ext_t ext_scale(ext_t a, gl_t s) { return ext_make(gl_mul(a.c0, s), gl_mul(a.c1, s)); }
+P2_HD bool ext_eq(ext_t a, ext_t b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+P2_HD ext_t ext_inv(ext_t a) {
+  gl_t norm = gl_sub(gl_sqr(a.c0), gl_mul_small(gl_sqr(a.c1), 7));
+  gl_t ni = gl_inv(norm);
+  return ext_make(gl_mul(a.c0, ni), gl_mul(gl_neg(a.c1), ni));
+}
+P2_HD ext_t ext_pow(ext_t b, uint64_t e) {
+  ext_t r = ext_from(1);
+  while (e) {
+    if (e & 1) r = ext_mul(r, b);
+    b = ext_mul(b, b);
+    e >>= 1;
+  }
+  return r;
+}
+
+}  // namespace p2

@@ -1,0 +1,135 @@
+/*
+ * p2gpu.h -- C ABI of libp2gpu.so: the MI355X (gfx950) implementation of the
+ * `prove` hot path of eryxcoop/acvm-backend-plonky2.
+ *
+ * What each entry point replaces in the reference (there is no FFI today; the
+ * seam is a Rust method call into the plonky2 crate):
+ *
+ *   p2gpu_circuit_create   <- the prover-side part of `builder.build::<C>()`
+ *                             plonky2-backend/src/circuit_translation/mod.rs:80-82
+ *                             (constants/sigmas LDE + Merkle tree, root tables,
+ *                             circuit digest), once per circuit
+ *   p2gpu_prove            <- `circuit_data.prove(witnesses).unwrap()`
+ *                             plonky2-backend/src/actions/prove_action.rs:91-97,
+ *                             after witness generation (input = full wire matrix)
+ *   p2gpu_prove_dev        <- same, wire matrix already resident in HBM
+ *   p2gpu_last_error       <- the `anyhow::Error` text the reference unwraps
+ *   p2gpu_ifft_batch / p2gpu_lde_batch / p2gpu_commit_values
+ *                          <- plonky2 PolynomialValues::ifft,
+ *                             PolynomialCoeffs::lde+coset_fft,
+ *                             PolynomialBatch::from_values (stage-level operators)
+ *
+ * Conventions: plain C, little-endian, field elements are canonical u64 < p =
+ * 2^64 - 2^32 + 1.  Return 0 = ok, < 0 = error (see P2GPU_E_*); no exception or
+ * abort crosses the ABI.  The caller owns every host buffer; the library owns
+ * device memory until p2gpu_circuit_destroy.  One in-flight prove per circuit
+ * handle; distinct handles may be used from distinct threads.
+ *
+ * ---------------------------------------------------------------------------
+ * Circuit blob (version 1), written once per circuit by the Rust side from
+ * CommonCircuitData + ProverOnlyCircuitData:
+ *
+ *   u32 header[64]:
+ *     [0] magic 0x43473250 "P2GC"   [1] version = 1      [2] degree_bits d
+ *     [3] num_wires                 [4] num_routed_wires  [5] num_constants (selector + gate-constant columns)
+ *     [6] num_selectors             [7] num_challenges    [8] quotient_degree_factor
+ *     [9] rate_bits                 [10] cap_height       [11] proof_of_work_bits
+ *     [12] num_query_rounds         [13] number of FRI reduction steps
+ *     [14..21] reduction_arity_bits [22] hasher (0 = KeccakHash<25>)
+ *     [23] num_gates                [24] num_public_inputs
+ *     [25] flags: bit0 = circuit_digest present, bit1 = constants_sigmas_cap present
+ *     [26] num_partial_products     [32..39] circuit_digest (25 bytes used)
+ *   u32 gate[num_gates][12]  in `common.gates` order:
+ *     kind, p0, p1, p2, p3, selector_index, group_start, group_end,
+ *     num_constraints, degree, num_constants, reserved
+ *   (flag bit1) u8 cap[2^cap_height][32]   expected constants_sigmas cap (25 bytes used)
+ *   u64 k_is[num_routed_wires]
+ *   u64 constants[num_constants][n]        values over the subgroup, column-major
+ *   u64 sigmas[num_routed_wires][n]
+ *
+ * Gate kinds (closed registry, plonky2-backend/src/actions/write_vk_action.rs:35-62):
+ *   0 Noop  1 Constant{p0=num_consts}  2 PublicInput  3 Arithmetic{p0=num_ops}
+ *   4 BaseSum{p0=B,p1=num_limbs}  5 RandomAccess{p0=bits,p1=copies,p2=extra_consts}
+ *   6 Poseidon (rejected for now)  7 U32Arithmetic{p0=num_ops}
+ *   8 U32AddMany{p0=num_addends,p1=num_ops}  9 U32Subtraction{p0=num_ops}
+ *   10 U32RangeCheck{p0=num_input_limbs}  11 Comparison{p0=num_bits,p1=num_chunks}
+ *
+ * Proof bytes: plonky2's uncompressed ProofWithPublicInputs::to_bytes layout
+ * (SURVEY.md C.11).  Compression (prove_action.rs:75-78) stays in Rust.
+ */
+#ifndef P2GPU_H
+#define P2GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2GPU_OK 0
+#define P2GPU_E_BLOB -1               /* malformed / unsupported circuit blob */
+#define P2GPU_E_BUFFER -2             /* output buffer too small (proof_len holds the size needed) */
+#define P2GPU_E_DEVICE -3             /* HIP error; see p2gpu_last_error */
+#define P2GPU_E_OPENING_IN_SUBGROUP -4 /* zeta^n == 1 ("Opening point is in the subgroup.") */
+#define P2GPU_E_UNSATISFIED -5        /* witness does not satisfy the circuit (self-check failed) */
+#define P2GPU_E_CAP_MISMATCH -6       /* constants_sigmas cap differs from the one in the blob */
+#define P2GPU_E_ARG -7
+#define P2GPU_E_NOT_INIT -8
+
+typedef struct p2gpu_circuit p2gpu_circuit;
+
+/* per-phase device time of the last proof (milliseconds, HIP events), phase
+ * names follow plonky2's TimingTree labels */
+typedef struct {
+  double wires_commit_ms;    /* "compute wires commitment" */
+  double zs_commit_ms;       /* "compute partial products" + commit */
+  double quotient_ms;        /* "compute quotient polys" + commit */
+  double openings_ms;        /* "construct the opening set" */
+  double fri_ms;             /* "compute opening proofs" */
+  double total_ms;           /* entry -> proof bytes on host */
+  double h2d_ms;             /* wire matrix upload (0 for p2gpu_prove_dev) */
+  uint64_t pow_witness;
+} p2gpu_timings;
+
+/* Select devices for this process (one process per GPU: pass one id).
+ * device_ids may be NULL for {current device}. */
+int p2gpu_init(const int *device_ids, int n_devices);
+
+int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out);
+void p2gpu_circuit_destroy(p2gpu_circuit *c);
+/* 2^cap_height x 25 bytes */
+int p2gpu_circuit_cap(const p2gpu_circuit *c, uint8_t *out);
+int p2gpu_circuit_digest(const p2gpu_circuit *c, uint8_t out[25]);
+/* upper bound of the proof size in bytes for this circuit */
+size_t p2gpu_proof_size_bound(const p2gpu_circuit *c);
+
+/* wires: host pointer, [num_wires][n] column-major.  proof_len: in = capacity,
+ * out = bytes used.  pow_hint: UINT64_MAX = grind for the minimum witness. */
+int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *public_inputs, uint32_t n_pi,
+                uint8_t *proof_out, size_t *proof_len, p2gpu_timings *opt_timings);
+/* same, `wires_dev` is a device pointer (e.g. torch tensor data_ptr) on the
+ * circuit's device; it is only read. */
+int p2gpu_prove_dev(p2gpu_circuit *c, const uint64_t *wires_dev, const uint64_t *public_inputs, uint32_t n_pi,
+                    uint8_t *proof_out, size_t *proof_len, p2gpu_timings *opt_timings);
+/* optional knobs: "pow_hint" (u64), "self_check" (0/1) */
+int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value);
+
+/* stage-level operators (host buffers in/out; used by the parity tests) */
+/* values [ncols][2^d] -> coefficients [ncols][2^d], natural order */
+int p2gpu_ifft_batch(const uint64_t *vals, size_t ncols, unsigned d, uint64_t *coeffs_out);
+/* coefficients [ncols][2^d] -> LDE values [ncols][2^(d+rate_bits)] on the coset 7<w>, natural order */
+int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned rate_bits, uint64_t *lde_out);
+/* PolynomialBatch::from_values: commit value columns, return the Merkle cap (2^cap_h x 25 B) */
+int p2gpu_commit_values(const uint64_t *vals, size_t ncols, unsigned d, unsigned rate_bits, unsigned cap_h,
+                        uint8_t *cap_out);
+/* KeccakHash<25>::hash_no_pad of `n_rows` rows of `row_len` elements (row-major) -> n_rows x 25 B */
+int p2gpu_hash_rows(const uint64_t *rows, size_t n_rows, size_t row_len, uint8_t *digests_out);
+
+const char *p2gpu_last_error(void);
+/* name/arch of the device in use, and peak numbers the bench prints */
+int p2gpu_device_info(char *name_out, size_t name_cap, int *cu_count, size_t *hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

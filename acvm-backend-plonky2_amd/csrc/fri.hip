@@ -1,0 +1,181 @@
+// fri.hip -- opening evaluation, FRI batch reduction, folding, proof-of-work
+// grinding and query gathers.
+//
+// Replaces, inside `circuit_data.prove` (plonky2-backend/src/actions/prove_action.rs:96):
+//   plonky2 0.2.2 plonk/proof.rs OpeningSet::new / PolynomialCoeffs::eval   
+//                 fri/oracle.rs  PolynomialBatch::prove_openings             (P11)
+//                 fri/prover.rs  fri_committed_trees, fri_proof_of_work,
+//                                fri_prover_query_rounds                     (P12)
+//
+// Coefficients live in bit-reversed positions (ntt.hip), so every coefficient
+// pass here is position-agnostic: openings are dot products with the table
+// zeta^(bitrev p); the batch combination sum_j alpha^j f_j is a column sweep;
+// (F(X) - F(z)) / (X - z) is taken pointwise on the size-n subgroup (z is never
+// in it) instead of by sequential synthetic division; the arity-16 fold reads
+// 16 unit-stride runs.  All HBM-bound streaming kernels.
+#include "internal.hpp"
+
+namespace p2 {
+
+__global__ void ext_powers_bitrev_kernel(ext_t base, uint32_t d, gl_t *out) {
+  const uint32_t n = 1u << d;
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint32_t e = bitrev32(p, d);
+  ext_t acc = ext_from(1), cur = base;
+  for (uint32_t b = 0; b < d; b++) {
+    if ((e >> b) & 1) acc = ext_mul(acc, cur);
+    cur = ext_mul(cur, cur);
+  }
+  out[p] = acc.c0;
+  out[(size_t)n + p] = acc.c1;
+}
+void ext_powers_bitrev(hipStream_t st, ext_t base, uint32_t d, gl_t *out) {
+  uint32_t n = 1u << d;
+  hipLaunchKernelGGL(ext_powers_bitrev_kernel, dim3((n + 255) / 256), dim3(256), 0, st, base, d, out);
+}
+
+// grid (parts, cols)
+__global__ __launch_bounds__(256) void eval_columns_kernel(const gl_t *__restrict__ coeffs, uint32_t d,
+                                                           const gl_t *__restrict__ pw, uint32_t parts,
+                                                           gl_t *__restrict__ partial) {
+  __shared__ gl_t s0[256], s1[256];
+  const uint32_t n = 1u << d;
+  const uint32_t part = blockIdx.x, col = blockIdx.y;
+  const uint32_t per = n / parts;
+  const gl_t *c = coeffs + (size_t)col * n + (size_t)part * per;
+  const gl_t *p0 = pw + (size_t)part * per, *p1 = pw + n + (size_t)part * per;
+  gl_t a0 = 0, a1 = 0;
+  for (uint32_t i = threadIdx.x; i < per; i += blockDim.x) {
+    gl_t v = c[i];
+    a0 = gl_add(a0, gl_mul(v, p0[i]));
+    a1 = gl_add(a1, gl_mul(v, p1[i]));
+  }
+  s0[threadIdx.x] = a0;
+  s1[threadIdx.x] = a1;
+  __syncthreads();
+  for (uint32_t off = blockDim.x >> 1; off; off >>= 1) {
+    if (threadIdx.x < off) {
+      s0[threadIdx.x] = gl_add(s0[threadIdx.x], s0[threadIdx.x + off]);
+      s1[threadIdx.x] = gl_add(s1[threadIdx.x], s1[threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[((size_t)col * parts + part) * 2] = s0[0];
+    partial[((size_t)col * parts + part) * 2 + 1] = s1[0];
+  }
+}
+void eval_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *pw, uint32_t parts,
+                  gl_t *partial) {
+  if (!cols) return;
+  ProfScope ps("eval_columns_kernel", 8.0 * cols * (double)((size_t)1 << d));
+  hipLaunchKernelGGL(eval_columns_kernel, dim3(parts, cols), dim3(256), 0, st, coeffs, d, pw, parts, partial);
+}
+
+__global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restrict__ coeffs, uint32_t cols, uint32_t d,
+                                                             const gl_t *__restrict__ apow, uint32_t j0,
+                                                             gl_t *__restrict__ acc, int accumulate) {
+  const uint32_t n = 1u << d;
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  gl_t a0 = accumulate ? acc[p] : 0, a1 = accumulate ? acc[(size_t)n + p] : 0;
+  for (uint32_t j = 0; j < cols; j++) {
+    gl_t v = coeffs[(size_t)j * n + p];
+    a0 = gl_add(a0, gl_mul(v, apow[2 * (j0 + j)]));
+    a1 = gl_add(a1, gl_mul(v, apow[2 * (j0 + j) + 1]));
+  }
+  acc[p] = a0;
+  acc[(size_t)n + p] = a1;
+}
+void reduce_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *apow, uint32_t j0,
+                    gl_t *acc, bool accumulate) {
+  uint32_t n = 1u << d;
+  uint32_t threads = n >= 256 ? 256 : 64;
+  ProfScope ps("reduce_columns_kernel", 8.0 * (cols + 4.0) * (double)n);
+  hipLaunchKernelGGL(reduce_columns_kernel, dim3((n + threads - 1) / threads), dim3(threads), 0, st, coeffs, cols, d,
+                     apow, j0, acc, accumulate ? 1 : 0);
+}
+
+__global__ __launch_bounds__(256) void fri_quotient_values_kernel(const gl_t *F0, const gl_t *F1, uint32_t d,
+                                                                  const gl_t *tw, uint32_t tw_shift, ext_t zeta,
+                                                                  ext_t gzeta, ext_t f0z, ext_t f1z, ext_t aK,
+                                                                  gl_t *out) {
+  const uint32_t n = 1u << d;
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t half = n >> 1;
+  gl_t x = d == 0 ? 1 : (k < half ? tw[(size_t)k << tw_shift] : gl_neg(tw[(size_t)(k - half) << tw_shift]));
+  ext_t v0 = ext_make(F0[k], F0[(size_t)n + k]), v1 = ext_make(F1[k], F1[(size_t)n + k]);
+  ext_t q0 = ext_mul(ext_sub(v0, f0z), ext_inv(ext_sub(ext_from(x), zeta)));
+  ext_t q1 = ext_mul(ext_sub(v1, f1z), ext_inv(ext_sub(ext_from(x), gzeta)));
+  ext_t r = ext_add(ext_mul(aK, q0), q1);
+  out[k] = r.c0;
+  out[(size_t)n + k] = r.c1;
+}
+void fri_quotient_values(hipStream_t st, const gl_t *F0, const gl_t *F1, uint32_t d, const gl_t *tw, uint32_t tw_shift,
+                         ext_t zeta, ext_t gzeta, ext_t f0z, ext_t f1z, ext_t aK, gl_t *out) {
+  uint32_t n = 1u << d;
+  uint32_t threads = n >= 256 ? 256 : 64;
+  hipLaunchKernelGGL(fri_quotient_values_kernel, dim3((n + threads - 1) / threads), dim3(threads), 0, st, F0, F1, d, tw,
+                     tw_shift, zeta, gzeta, f0z, f1z, aK, out);
+}
+
+// coefficients c[j] live at bitrev_d(j).  out[q] (= c'[bitrev_{d-ab}(q)... ]) =
+// sum_t beta^t c[arity * m + t] with q = bitrev(m): source position bitrev_ab(t) * n' + q.
+__global__ __launch_bounds__(256) void fri_fold_kernel(const gl_t *in, uint32_t d, uint32_t ab, ext_t beta, gl_t *out) {
+  const uint32_t n = 1u << d, n2 = n >> ab, arity = 1u << ab;
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n2) return;
+  ext_t acc = ext_from(0);
+  for (uint32_t t = arity; t-- > 0;) {
+    size_t pos = (size_t)bitrev32(t, ab) * n2 + q;
+    acc = ext_add(ext_mul(acc, beta), ext_make(in[pos], in[(size_t)n + pos]));
+  }
+  out[q] = acc.c0;
+  out[(size_t)n2 + q] = acc.c1;
+}
+void fri_fold(hipStream_t st, const gl_t *in, uint32_t d, uint32_t ab, ext_t beta, gl_t *out) {
+  uint32_t n2 = (1u << d) >> ab;
+  uint32_t threads = n2 >= 256 ? 256 : 64;
+  hipLaunchKernelGGL(fri_fold_kernel, dim3((n2 + threads - 1) / threads), dim3(threads), 0, st, in, d, ab, beta, out);
+}
+
+struct PowState {
+  gl_t s[12];
+};
+__global__ __launch_bounds__(256) void pow_kernel(PowState st0, uint32_t pos, uint32_t pow_bits, uint64_t base,
+                                                  uint64_t count, unsigned long long *result) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint64_t w = base + i;
+  gl_t st[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) st[j] = st0.s[j];
+#pragma unroll
+  for (int j = 0; j < 12; j++)
+    if ((uint32_t)j == pos) st[j] = w;
+  keccak_permutation12(st);
+  const uint64_t resp = st[7];
+  if (pow_bits == 0 || (resp >> (64 - pow_bits)) == 0) atomicMin(result, (unsigned long long)w);
+}
+void pow_search(hipStream_t st, const gl_t state[12], uint32_t pos, uint32_t pow_bits, uint64_t base, uint64_t count,
+                unsigned long long *result) {
+  PowState s;
+  for (int i = 0; i < 12; i++) s.s[i] = state[i];
+  ProfScope ps("pow_kernel", 0.0);
+  hipLaunchKernelGGL(pow_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, s, pos, pow_bits, base, count,
+                     result);
+}
+
+__global__ void gather_kernel(const uint64_t *addr, uint32_t count, gl_t *out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = *(const gl_t *)(uintptr_t)addr[i];
+}
+void gather_u64(hipStream_t st, const uint64_t *addr, uint32_t count, gl_t *out) {
+  if (!count) return;
+  ProfScope ps("gather_kernel", 24.0 * count);
+  hipLaunchKernelGGL(gather_kernel, dim3((count + 255) / 256), dim3(256), 0, st, addr, count, out);
+}
+
+}  // namespace p2

@@ -1,0 +1,118 @@
+// internal.hpp -- declarations shared by the HIP translation units of libp2gpu.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gl.hpp"
+#include "keccak.hpp"
+
+namespace p2 {
+
+enum {
+  G_NOOP = 0, G_CONSTANT = 1, G_PUBLIC_INPUT = 2, G_ARITHMETIC = 3, G_BASE_SUM = 4, G_RANDOM_ACCESS = 5,
+  G_POSEIDON = 6, G_U32_ARITHMETIC = 7, G_U32_ADD_MANY = 8, G_U32_SUBTRACTION = 9, G_U32_RANGE_CHECK = 10,
+  G_COMPARISON = 11, G_KIND_COUNT
+};
+
+struct GateDesc {
+  uint32_t kind, p[4];
+  uint32_t sel_index, group_start, group_end;
+  uint32_t num_constraints, degree, num_constants, pad;
+};
+constexpr int MAX_GATES = 32;
+constexpr int MAX_CHALLENGES = 2;
+constexpr int MAX_ROUTED = 128;
+
+// ---- per-launch profiling hook (HIP events on the launch stream, see prover.hip) ----
+struct Prof {
+  virtual void begin(const char *kernel, double algorithmic_bytes) = 0;
+  virtual void end() = 0;
+  virtual ~Prof() {}
+};
+extern thread_local Prof *g_prof;
+struct ProfScope {
+  ProfScope(const char *k, double bytes) { if (g_prof) g_prof->begin(k, bytes); }
+  ~ProfScope() { if (g_prof) g_prof->end(); }
+};
+
+// ---- ntt.hip ----
+// dit = 0: DIF, natural in -> bit-reversed out; dit = 1: DIT, bit-reversed in -> natural out.
+// src [cols][n] (or [cosets][cols][n] when src_per_coset), dst [cosets][cols][n].
+// tw: powers of the (forward or inverse) primitive root of a size n << tw_shift.
+// scale (DIT only): [cosets][n] multiplied into the input; post: multiplied into the output.
+void ntt_batch(hipStream_t st, int dit, const gl_t *src, gl_t *dst, uint32_t d, uint32_t cols, uint32_t cosets,
+               const gl_t *tw, uint32_t tw_shift, const gl_t *scale, gl_t post, bool src_per_coset);
+void fill_powers(hipStream_t st, gl_t *out, gl_t root, uint32_t count);
+void fill_coset_scale(hipStream_t st, gl_t *out, gl_t shift, gl_t wN, uint32_t d, uint32_t cosets, gl_t mult);
+void bitrev_cols(hipStream_t st, const gl_t *in, gl_t *out, uint32_t d, uint32_t cols);
+
+// ---- merkle.hip ----
+// leaf digests of an LDE batch: lde [cosets][cols][n] -> dig [cosets][n]
+void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig);
+// row-major rows (stage-level operator)
+void hash_rows(hipStream_t st, const gl_t *rows, size_t n_rows, uint32_t row_len, dig_t *dig);
+// FRI step leaves: vals [cosets][2][npc] (ext coordinates), leaf = 16 ext values; dig [cosets][npc/16]
+void hash_fri_leaves(hipStream_t st, const gl_t *vals, uint32_t lg_npc, uint32_t cosets, uint32_t arity_bits,
+                     dig_t *dig);
+// one tree level: in [cosets][m] -> out [cosets][m/2], out[c][k] = H(in[c][k], in[c][k + m/2])
+void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m);
+
+// ---- plonk.hip ----
+struct ZsArgs {
+  const gl_t *wires;   // [W][n] values
+  const gl_t *sigmas;  // [R][n] values
+  const gl_t *k_is;    // [R]
+  const gl_t *sub_tw;  // w_n^i, i < n/2 (forward table, shift tw_shift)
+  uint32_t tw_shift;
+  uint32_t d, R, QF, nchunks, K;
+  gl_t betas[MAX_CHALLENGES], gammas[MAX_CHALLENGES];
+  gl_t *cp;      // [K][nchunks][n] chunk quotients (scratch)
+  gl_t *rowprod; // [K][n]
+  gl_t *zp;      // out [K*(1+PP)][n]
+};
+void zs_partial_products(hipStream_t st, const ZsArgs &a, gl_t *scan_tmp);
+
+struct QuotArgs {
+  const gl_t *cs_lde;    // [cosets][NC+R][n]
+  const gl_t *wires_lde; // [cosets][W][n]
+  const gl_t *zp_lde;    // [cosets][K*(1+PP)][n]
+  const gl_t *k_is;      // [R]
+  const gl_t *tw;        // w_n^i forward table
+  const gl_t *apow;      // [K][nterms] alpha powers
+  const GateDesc *gates; // device copy
+  gl_t *out;             // [K][cosets][n]
+  uint32_t tw_shift, d, rate_bits, W, R, NC, num_selectors, K, QF, nchunks, PP, num_gates, nterms;
+  gl_t betas[MAX_CHALLENGES], gammas[MAX_CHALLENGES];
+  gl_t pi_hash[4];
+  gl_t coset_shift[8];  // 7 * w_N^r
+  gl_t zh_inv[8];       // 1 / (7^n w_8^r - 1)
+  gl_t zh[8];
+  gl_t n_inv;           // 1/n
+};
+void quotient_eval(hipStream_t st, const QuotArgs &a);
+// cross-coset inverse butterflies.  in [K][C][n]: per-coset inverse transforms of
+// the quotient values (bit-reversed coefficient storage, C = 2^rate_bits);
+// inv_scale [C][n] = (1/s_r)^(bitrev p); out [K*C][n]: chunk polynomials
+// Q_m = 7^(-n m) / C * sum_r w_C^(-r m) P_r.
+void quotient_chunks(hipStream_t st, const gl_t *in, const gl_t *inv_scale, gl_t *out, uint32_t d, uint32_t K,
+                     uint32_t rate_bits, gl_t w_inv, gl_t gn_inv, gl_t rate_inv);
+
+// ---- fri.hip ----
+// pw[p] = base^(bitrev_d(p)) over the extension: out [2][n]
+void ext_powers_bitrev(hipStream_t st, ext_t base, uint32_t d, gl_t *out);
+// partial dot products: for each column c of coeffs [cols][n]: sum_p coeffs[c][p] * pw[p]; parts per column
+void eval_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *pw, uint32_t parts,
+                  gl_t *partial /* [cols][parts][2] */);
+// acc[2][n] (+)= sum_j apow[j0 + j] * coeffs[j][p]
+void reduce_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *apow /*[.][2]*/,
+                    uint32_t j0, gl_t *acc, bool accumulate);
+// final[k] = aK * (F0[k] - f0z) / (x_k - zeta) + (F1[k] - f1z) / (x_k - gzeta), x_k = w_n^k
+void fri_quotient_values(hipStream_t st, const gl_t *F0, const gl_t *F1, uint32_t d, const gl_t *tw, uint32_t tw_shift,
+                         ext_t zeta, ext_t gzeta, ext_t f0z, ext_t f1z, ext_t aK, gl_t *out /*[2][n]*/);
+// coefficient fold in bit-reversed storage: out[q] = sum_t beta^t in[bitrev4(t) * n/16 + q]
+void fri_fold(hipStream_t st, const gl_t *in /*[2][n]*/, uint32_t d, uint32_t arity_bits, ext_t beta, gl_t *out);
+// proof of work: smallest w in [base, base + count) with leading zeros; result via atomicMin
+void pow_search(hipStream_t st, const gl_t state[12], uint32_t pos, uint32_t pow_bits, uint64_t base, uint64_t count,
+                unsigned long long *result);
+// gather: out[i] = *(const u64 *)addr[i] (absolute device addresses)
+void gather_u64(hipStream_t st, const uint64_t *addr, uint32_t count, gl_t *out);
+
+}  // namespace p2

@@ -1,0 +1,149 @@
+// keccak.hpp -- Keccak-f[1600] with the state held in registers (25 x u64 = 50
+// VGPRs on gfx950), Keccak-256 for host-side transcript work, and the 25-byte
+// truncated digests of plonky2's KeccakHash<25> (hash/keccak.rs in the
+// un-vendored plonky2 0.2.2; the reference selects it at
+// plonky2-backend/src/lib.rs:13 `type C = KeccakGoldilocksConfig`).
+// Original Keccak padding (0x01 .. 0x80), not SHA-3.
+//
+// Integer-ALU bound: ~24 x (theta 50 + rho/pi 24 rot + chi 75 + iota) 64-bit ops
+// per permutation; rotates compile to v_alignbit_b32 pairs.  One lane owns one
+// sponge; lanes of a wave hash 64 independent leaves.
+#pragma once
+#include "gl.hpp"
+
+namespace p2 {
+
+// digests are stored as 4 x u64 (32 B) in device memory; only the first 25
+// bytes are significant and the 7 top bytes of word 3 are kept zero.
+struct alignas(32) dig_t {
+  uint64_t w[4];
+};
+
+P2_HD uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+#define P2_KECCAK_ROUND(RC)                                                                                            \
+  {                                                                                                                    \
+    uint64_t c0 = a00 ^ a05 ^ a10 ^ a15 ^ a20, c1 = a01 ^ a06 ^ a11 ^ a16 ^ a21, c2 = a02 ^ a07 ^ a12 ^ a17 ^ a22,       \
+             c3 = a03 ^ a08 ^ a13 ^ a18 ^ a23, c4 = a04 ^ a09 ^ a14 ^ a19 ^ a24;                                        \
+    uint64_t d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1), d3 = c2 ^ rotl64(c4, 1),       \
+             d4 = c3 ^ rotl64(c0, 1);                                                                                  \
+    a00 ^= d0; a05 ^= d0; a10 ^= d0; a15 ^= d0; a20 ^= d0;                                                             \
+    a01 ^= d1; a06 ^= d1; a11 ^= d1; a16 ^= d1; a21 ^= d1;                                                             \
+    a02 ^= d2; a07 ^= d2; a12 ^= d2; a17 ^= d2; a22 ^= d2;                                                             \
+    a03 ^= d3; a08 ^= d3; a13 ^= d3; a18 ^= d3; a23 ^= d3;                                                             \
+    a04 ^= d4; a09 ^= d4; a14 ^= d4; a19 ^= d4; a24 ^= d4;                                                             \
+    /* rho + pi: B[y][2x+3y] = rot(A[x][y]) */                                                                         \
+    uint64_t b00 = a00, b10 = rotl64(a01, 1), b20 = rotl64(a02, 62), b05 = rotl64(a03, 28), b15 = rotl64(a04, 27);     \
+    uint64_t b16 = rotl64(a05, 36), b01 = rotl64(a06, 44), b11 = rotl64(a07, 6), b21 = rotl64(a08, 55),                \
+             b06 = rotl64(a09, 20);                                                                                    \
+    uint64_t b07 = rotl64(a10, 3), b17 = rotl64(a11, 10), b02 = rotl64(a12, 43), b12 = rotl64(a13, 25),                \
+             b22 = rotl64(a14, 39);                                                                                    \
+    uint64_t b23 = rotl64(a15, 41), b08 = rotl64(a16, 45), b18 = rotl64(a17, 15), b03 = rotl64(a18, 21),               \
+             b13 = rotl64(a19, 8);                                                                                     \
+    uint64_t b14 = rotl64(a20, 18), b24 = rotl64(a21, 2), b09 = rotl64(a22, 61), b19 = rotl64(a23, 56),                \
+             b04 = rotl64(a24, 14);                                                                                    \
+    a00 = b00 ^ (~b01 & b02); a01 = b01 ^ (~b02 & b03); a02 = b02 ^ (~b03 & b04); a03 = b03 ^ (~b04 & b00);            \
+    a04 = b04 ^ (~b00 & b01);                                                                                          \
+    a05 = b05 ^ (~b06 & b07); a06 = b06 ^ (~b07 & b08); a07 = b07 ^ (~b08 & b09); a08 = b08 ^ (~b09 & b05);            \
+    a09 = b09 ^ (~b05 & b06);                                                                                          \
+    a10 = b10 ^ (~b11 & b12); a11 = b11 ^ (~b12 & b13); a12 = b12 ^ (~b13 & b14); a13 = b13 ^ (~b14 & b10);            \
+    a14 = b14 ^ (~b10 & b11);                                                                                          \
+    a15 = b15 ^ (~b16 & b17); a16 = b16 ^ (~b17 & b18); a17 = b17 ^ (~b18 & b19); a18 = b18 ^ (~b19 & b15);            \
+    a19 = b19 ^ (~b15 & b16);                                                                                          \
+    a20 = b20 ^ (~b21 & b22); a21 = b21 ^ (~b22 & b23); a22 = b22 ^ (~b23 & b24); a23 = b23 ^ (~b24 & b20);            \
+    a24 = b24 ^ (~b20 & b21);                                                                                          \
+    a00 ^= (RC);                                                                                                       \
+  }
+
+// st[x + 5y]
+P2_HD void keccak_f1600(uint64_t st[25]) {
+  const uint64_t RC[24] = {
+      0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+      0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+      0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+      0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+      0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+      0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+  uint64_t a00 = st[0], a01 = st[1], a02 = st[2], a03 = st[3], a04 = st[4], a05 = st[5], a06 = st[6], a07 = st[7],
+           a08 = st[8], a09 = st[9], a10 = st[10], a11 = st[11], a12 = st[12], a13 = st[13], a14 = st[14],
+           a15 = st[15], a16 = st[16], a17 = st[17], a18 = st[18], a19 = st[19], a20 = st[20], a21 = st[21],
+           a22 = st[22], a23 = st[23], a24 = st[24];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 2
+#endif
+  for (int r = 0; r < 24; r++) P2_KECCAK_ROUND(RC[r])
+  st[0] = a00; st[1] = a01; st[2] = a02; st[3] = a03; st[4] = a04; st[5] = a05; st[6] = a06; st[7] = a07;
+  st[8] = a08; st[9] = a09; st[10] = a10; st[11] = a11; st[12] = a12; st[13] = a13; st[14] = a14; st[15] = a15;
+  st[16] = a16; st[17] = a17; st[18] = a18; st[19] = a19; st[20] = a20; st[21] = a21; st[22] = a22; st[23] = a23;
+  st[24] = a24;
+}
+
+// Keccak-256 over `nwords` little-endian u64 words (every message on the prove
+// path is a whole number of words).  Host + device.
+P2_HD void keccak256_words(const uint64_t *in, size_t nwords, uint64_t out[4]) {
+  uint64_t st[25];
+  for (int i = 0; i < 25; i++) st[i] = 0;
+  size_t off = 0;
+  while (nwords - off >= 17) {
+    for (int i = 0; i < 17; i++) st[i] ^= in[off + i];
+    keccak_f1600(st);
+    off += 17;
+  }
+  size_t rem = nwords - off;
+  for (size_t i = 0; i < rem; i++) st[i] ^= in[off + i];
+  st[rem] ^= 0x01ULL;
+  st[16] ^= 0x8000000000000000ULL;
+  keccak_f1600(st);
+  for (int i = 0; i < 4; i++) out[i] = st[i];
+}
+
+P2_HD dig_t dig_from_state(const uint64_t st[4]) {
+  dig_t d;
+  d.w[0] = st[0];
+  d.w[1] = st[1];
+  d.w[2] = st[2];
+  d.w[3] = st[3] & 0xFFULL;
+  return d;
+}
+
+// KeccakHash<25>::two_to_one: Keccak-256(left[25] || right[25])[..25]
+P2_HD dig_t keccak_two_to_one(const dig_t &l, const dig_t &r) {
+  uint64_t st[25];
+  for (int i = 0; i < 25; i++) st[i] = 0;
+  st[0] = l.w[0];
+  st[1] = l.w[1];
+  st[2] = l.w[2];
+  st[3] = (l.w[3] & 0xFFULL) | (r.w[0] << 8);
+  st[4] = (r.w[0] >> 56) | (r.w[1] << 8);
+  st[5] = (r.w[1] >> 56) | (r.w[2] << 8);
+  st[6] = (r.w[2] >> 56) | ((r.w[3] & 0xFFULL) << 8) | (0x01ULL << 16);
+  st[16] = 0x8000000000000000ULL;
+  keccak_f1600(st);
+  return dig_from_state(st);
+}
+
+// BytesHash<25>::to_vec: 7-byte little-endian chunks -> 4 field elements
+P2_HD void dig_to_elems(const dig_t &d, gl_t out[4]) {
+  const uint64_t M56 = 0x00FFFFFFFFFFFFFFULL;
+  out[0] = d.w[0] & M56;
+  out[1] = ((d.w[0] >> 56) | (d.w[1] << 8)) & M56;
+  out[2] = ((d.w[1] >> 48) | (d.w[2] << 16)) & M56;
+  out[3] = ((d.w[2] >> 40) | ((d.w[3] & 0xFF) << 24)) & 0xFFFFFFFFULL;
+}
+
+// KeccakPermutation::permute ("hash onion" with rejection sampling)
+P2_HD void keccak_permutation12(gl_t st[12]) {
+  uint64_t h[4];
+  keccak256_words(st, 12, h);
+  int got = 0;
+  for (;;) {
+    for (int i = 0; i < 4 && got < 12; i++)
+      if (h[i] < GL_P) st[got++] = h[i];
+    if (got == 12) break;
+    uint64_t h2[4];
+    keccak256_words(h, 4, h2);
+    for (int i = 0; i < 4; i++) h[i] = h2[i];
+  }
+}
+
+}  // namespace p2

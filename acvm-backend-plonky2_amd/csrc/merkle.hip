@@ -1,0 +1,125 @@
+// merkle.hip -- Keccak-256/25 leaf and node hashing for the Merkle commitments.
+//
+// Replaces plonky2 0.2.2 hash/merkle_tree.rs MerkleTree::new (+ KeccakHash<25>::
+// hash_or_noop / two_to_one) inside `circuit_data.prove`
+// (plonky2-backend/src/actions/prove_action.rs:96), SURVEY.md 8a rows P4/P5.
+//
+// plonky2 transposes the LDE to leaf-major rows and bit-reverses them before
+// hashing.  Here the LDE stays column-major per coset ([coset][col][k]): lane
+// <-> k, so every column read is a fully coalesced 512 B wave access, and the
+// leaf digest of natural row i = 8k + r is stored at [r][k].  plonky2's leaf
+// index bitrev(i) = bitrev3(r) * n + bitrev_d(k) means tree level l pairs
+// nodes k and k + n/2^l of the same coset: the tree is built level by level
+// with unit-stride accesses and no bit reversal; only the cap entries are
+// permuted on the host (cap[2*bitrev3(r) + k] for cap_height 4).
+// Integer-ALU bound (Keccak-f ~ 8k 32-bit ops per 136 B), not HBM bound.
+#include "internal.hpp"
+
+namespace p2 {
+
+template <class F>
+__device__ __forceinline__ dig_t sponge_hash(uint32_t nwords, F get) {
+  uint64_t st[25];
+#pragma unroll
+  for (int i = 0; i < 25; i++) st[i] = 0;
+  uint32_t off = 0;
+  while (nwords - off >= 17) {
+#pragma unroll
+    for (int w = 0; w < 17; w++) st[w] ^= get(off + w);
+    keccak_f1600(st);
+    off += 17;
+  }
+  const uint32_t rem = nwords - off;
+#pragma unroll
+  for (int w = 0; w < 17; w++) {
+    if ((uint32_t)w < rem) st[w] ^= get(off + w);
+    if ((uint32_t)w == rem) st[w] ^= 0x01ULL;
+  }
+  st[16] ^= 0x8000000000000000ULL;
+  keccak_f1600(st);
+  return dig_from_state(st);
+}
+
+// hash_or_noop: rows of <= 3 elements are copied, not hashed
+template <class F>
+__device__ __forceinline__ dig_t hash_or_noop(uint32_t nwords, F get) {
+  if (nwords * 8 <= 25) {
+    dig_t d;
+    d.w[0] = nwords > 0 ? get(0) : 0;
+    d.w[1] = nwords > 1 ? get(1) : 0;
+    d.w[2] = nwords > 2 ? get(2) : 0;
+    d.w[3] = 0;
+    return d;
+  }
+  return sponge_hash(nwords, get);
+}
+
+__global__ __launch_bounds__(256) void hash_lde_leaves_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
+                                                              dig_t *__restrict__ dig) {
+  const size_t n = (size_t)1 << d;
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = blockIdx.y;
+  if (k >= n) return;
+  const gl_t *base = lde + (size_t)c * cols * n + k;
+  dig[(size_t)c * n + k] = hash_or_noop(cols, [&](uint32_t i) { return base[(size_t)i * n]; });
+}
+
+__global__ __launch_bounds__(256) void hash_rows_kernel(const gl_t *__restrict__ rows, size_t n_rows, uint32_t row_len,
+                                                        dig_t *__restrict__ dig) {
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const gl_t *base = rows + r * row_len;
+  dig[r] = hash_or_noop(row_len, [&](uint32_t i) { return base[i]; });
+}
+
+// leaf (r, kl): ext values at k = bitrev_ab(t) * (npc >> ab) + kl, t < 2^ab, flattened (c0, c1)
+__global__ __launch_bounds__(256) void hash_fri_leaves_kernel(const gl_t *__restrict__ vals, uint32_t lg_npc,
+                                                              uint32_t ab, dig_t *__restrict__ dig) {
+  const uint32_t npc = 1u << lg_npc, per = npc >> ab;
+  const uint32_t kl = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t r = blockIdx.y;
+  if (kl >= per) return;
+  const gl_t *c0 = vals + (size_t)r * 2 * npc, *c1 = c0 + npc;
+  dig[(size_t)r * per + kl] = hash_or_noop(2u << ab, [&](uint32_t w) {
+    uint32_t t = w >> 1;
+    uint32_t k = bitrev32(t, ab) * per + kl;
+    return (w & 1) ? c1[k] : c0[k];
+  });
+}
+
+__global__ __launch_bounds__(256) void merkle_level_kernel(const dig_t *__restrict__ in, dig_t *__restrict__ out,
+                                                           uint32_t m) {
+  const uint32_t half = m >> 1;
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = blockIdx.y;
+  if (k >= half) return;
+  const dig_t l = in[(size_t)c * m + k], r = in[(size_t)c * m + k + half];
+  out[(size_t)c * half + k] = keccak_two_to_one(l, r);
+}
+
+void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig) {
+  size_t n = (size_t)1 << d;
+  uint32_t threads = n >= 256 ? 256 : 64;
+  ProfScope ps("hash_lde_leaves_kernel", (8.0 * cols + 32.0) * cosets * (double)n);
+  hipLaunchKernelGGL(hash_lde_leaves_kernel, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols,
+                     d, dig);
+}
+void hash_rows(hipStream_t st, const gl_t *rows, size_t n_rows, uint32_t row_len, dig_t *dig) {
+  hipLaunchKernelGGL(hash_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, st, rows, n_rows, row_len, dig);
+}
+void hash_fri_leaves(hipStream_t st, const gl_t *vals, uint32_t lg_npc, uint32_t cosets, uint32_t ab, dig_t *dig) {
+  uint32_t per = (1u << lg_npc) >> ab;
+  uint32_t threads = per >= 256 ? 256 : 64;
+  ProfScope ps("hash_fri_leaves_kernel", (16.0 * (1u << ab) + 32.0) * cosets * (double)per);
+  hipLaunchKernelGGL(hash_fri_leaves_kernel, dim3((per + threads - 1) / threads, cosets), dim3(threads), 0, st, vals,
+                     lg_npc, ab, dig);
+}
+void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m) {
+  uint32_t half = m >> 1;
+  uint32_t threads = half >= 256 ? 256 : 64;
+  ProfScope ps("merkle_level_kernel", 96.0 * cosets * (double)half);
+  hipLaunchKernelGGL(merkle_level_kernel, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out,
+                     m);
+}
+
+}  // namespace p2

@@ -1,0 +1,460 @@
+// plonk.hip -- permutation argument (Z / partial products) and the
+// vanishing-polynomial / quotient evaluation over the LDE domain.
+//
+// Replaces, inside `circuit_data.prove` (plonky2-backend/src/actions/prove_action.rs:96):
+//   plonky2 0.2.2 plonk/prover.rs  wires_permutation_partial_products_and_zs
+//                                  compute_quotient_polys                    (P9)
+//                 plonk/vanishing_poly.rs eval_vanishing_poly_base_batch,
+//                                  evaluate_gate_constraints_base_batch
+//                 gates/selectors.rs compute_filter
+// and restates the constraint formulas of the reference's in-tree custom gates:
+//   plonky2-backend/src/plonky2_ecdsa/biguint/gates/arithmetic_u32.rs:289-348
+//   .../add_many_u32.rs:151-192, subtraction_u32.rs:234-270,
+//   .../range_check_u32.rs:95-117, comparison.rs:337-414
+// plus the stock gates the translator emits.
+//
+// Layout: one lane per LDE row (coset r, index k); every column access
+// lde[r][col][k] is unit-stride across the wave.  Each gate's constraints are
+// folded straight into the two alpha-combinations (sum_t alpha_c^t term_t) with
+// a precomputed alpha-power table read through scalar loads, so no per-row
+// constraint vector is ever materialised.  Z(g x) is row k+1 of the same coset
+// (i + 8 = 8(k+1) + r): no halo.  Integer-ALU bound (modmuls), not MFMA.
+#include "internal.hpp"
+
+namespace p2 {
+
+// ------------------------------------------------------------------------------
+// x = w_n^i from the half table tw[j << shift] = w_n^j, j < n/2
+__device__ __forceinline__ gl_t root_pow(const gl_t *tw, uint32_t shift, uint32_t d, uint32_t i) {
+  uint32_t half = 1u << (d - 1);
+  if (d == 0) return 1;
+  return i < half ? tw[(size_t)i << shift] : gl_neg(tw[(size_t)(i - half) << shift]);
+}
+
+// ---- Z / partial products -------------------------------------------------------
+__global__ __launch_bounds__(256) void zs_chunk_kernel(ZsArgs a) {
+  const uint32_t n = 1u << a.d;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = blockIdx.y;
+  if (i >= n) return;
+  const gl_t x = root_pow(a.sub_tw, a.tw_shift, a.d, i);
+  const gl_t beta = a.betas[c], gamma = a.gammas[c];
+  const gl_t bx = gl_mul(beta, x);
+  gl_t np[16], dp[16];
+  for (uint32_t m = 0; m < a.nchunks; m++) {
+    gl_t pn = 1, pd = 1;
+    for (uint32_t j = m * a.QF; j < (m + 1) * a.QF && j < a.R; j++) {
+      gl_t wv = a.wires[(size_t)j * n + i];
+      gl_t num = gl_add(gl_add(wv, gl_mul(bx, a.k_is[j])), gamma);
+      gl_t den = gl_add(gl_add(wv, gl_mul(beta, a.sigmas[(size_t)j * n + i])), gamma);
+      pn = gl_mul(pn, num);
+      pd = gl_mul(pd, den);
+    }
+    np[m] = pn;
+    dp[m] = pd;
+  }
+  // Montgomery batch inversion of the chunk denominators
+  gl_t pre[16];
+  gl_t acc = 1;
+  for (uint32_t m = 0; m < a.nchunks; m++) {
+    pre[m] = acc;
+    acc = gl_mul(acc, dp[m]);
+  }
+  gl_t inv = gl_inv(acc);
+  gl_t rowp = 1;
+  for (uint32_t m = a.nchunks; m-- > 0;) {
+    gl_t di = gl_mul(inv, pre[m]);
+    inv = gl_mul(inv, dp[m]);
+    gl_t q = gl_mul(np[m], di);
+    a.cp[((size_t)c * a.nchunks + m) * n + i] = q;
+    rowp = gl_mul(rowp, q);
+  }
+  a.rowprod[(size_t)c * n + i] = rowp;
+}
+
+// exclusive multiplicative scan across a block (blockDim <= 1024)
+__device__ __forceinline__ gl_t block_scan_mul(gl_t v, gl_t *lds, gl_t *total) {
+  const uint32_t t = threadIdx.x, nt = blockDim.x;
+  lds[t] = v;
+  __syncthreads();
+  for (uint32_t off = 1; off < nt; off <<= 1) {
+    gl_t x = lds[t];
+    gl_t y = t >= off ? lds[t - off] : 1;
+    __syncthreads();
+    lds[t] = gl_mul(x, y);
+    __syncthreads();
+  }
+  gl_t incl = lds[t];
+  gl_t excl = t ? lds[t - 1] : 1;
+  *total = lds[nt - 1];
+  (void)incl;
+  return excl;
+}
+
+__global__ __launch_bounds__(256) void scan_local_kernel(const gl_t *rowprod, uint32_t n, gl_t *local, gl_t *bsum,
+                                                         uint32_t nblocks) {
+  __shared__ gl_t lds[256];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = blockIdx.y;
+  gl_t v = i < n ? rowprod[(size_t)c * n + i] : 1;
+  gl_t total;
+  gl_t excl = block_scan_mul(v, lds, &total);
+  if (i < n) local[(size_t)c * n + i] = excl;
+  if (threadIdx.x == 0) bsum[(size_t)c * nblocks + blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(gl_t *bsum, uint32_t nblocks) {
+  __shared__ gl_t lds[1024];
+  const uint32_t c = blockIdx.x;
+  gl_t *b = bsum + (size_t)c * nblocks;
+  const uint32_t per = (nblocks + blockDim.x - 1) / blockDim.x;
+  const uint32_t lo = threadIdx.x * per;
+  gl_t prod = 1;
+  for (uint32_t j = lo; j < lo + per && j < nblocks; j++) prod = gl_mul(prod, b[j]);
+  gl_t total;
+  gl_t excl = block_scan_mul(prod, lds, &total);
+  gl_t acc = excl;
+  for (uint32_t j = lo; j < lo + per && j < nblocks; j++) {
+    gl_t v = b[j];
+    b[j] = acc;  // exclusive prefix of block j
+    acc = gl_mul(acc, v);
+  }
+}
+__global__ __launch_bounds__(256) void zs_finish_kernel(ZsArgs a, const gl_t *local, const gl_t *bpre,
+                                                        uint32_t nblocks) {
+  const uint32_t n = 1u << a.d;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = blockIdx.y;
+  if (i >= n) return;
+  const uint32_t PP = a.nchunks - 1;
+  gl_t z = gl_mul(bpre[(size_t)c * nblocks + blockIdx.x], local[(size_t)c * n + i]);
+  a.zp[(size_t)c * n + i] = z;
+  gl_t acc = z;
+  for (uint32_t m = 0; m < PP; m++) {
+    acc = gl_mul(acc, a.cp[((size_t)c * a.nchunks + m) * n + i]);
+    a.zp[((size_t)a.K + (size_t)c * PP + m) * n + i] = acc;
+  }
+}
+
+// scan_tmp: at least K * (n + ceil(n/256)) elements
+void zs_partial_products(hipStream_t st, const ZsArgs &a, gl_t *scan_tmp) {
+  const uint32_t n = 1u << a.d;
+  const uint32_t threads = 256;
+  const uint32_t nblocks = (n + threads - 1) / threads;
+  gl_t *local = scan_tmp;
+  gl_t *bsum = scan_tmp + (size_t)a.K * n;
+  {
+  ProfScope ps("zs_chunk_kernel", 8.0 * a.K * (double)n * (2.0 * a.R + a.nchunks + 1));
+  hipLaunchKernelGGL(zs_chunk_kernel, dim3(nblocks, a.K), dim3(threads), 0, st, a);
+  }
+  ProfScope ps2("zs_scan_finish", 8.0 * a.K * (double)n * (2.0 * a.nchunks + 4));
+  hipLaunchKernelGGL(scan_local_kernel, dim3(nblocks, a.K), dim3(threads), 0, st, a.rowprod, n, local, bsum, nblocks);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(a.K), dim3(1024), 0, st, bsum, nblocks);
+  hipLaunchKernelGGL(zs_finish_kernel, dim3(nblocks, a.K), dim3(threads), 0, st, a, local, bsum, nblocks);
+}
+
+// ---- gate constraints -------------------------------------------------------------
+struct Consumer {
+  gl_t acc0, acc1;
+  const gl_t *ap0, *ap1;
+  uint32_t t;
+  __device__ __forceinline__ void emit(gl_t c) {
+    acc0 = gl_add(acc0, gl_mul(ap0[t], c));
+    acc1 = gl_add(acc1, gl_mul(ap1[t], c));
+    t++;
+  }
+};
+
+__device__ __forceinline__ gl_t range_product(gl_t v, uint32_t base) {
+  gl_t p = v;
+  for (uint32_t x = 1; x < base; x++) p = gl_mul(p, gl_sub(v, x));
+  return p;
+}
+__device__ __forceinline__ gl_t range4(gl_t v) {
+  // v (v-1) (v-2) (v-3)
+  gl_t a = gl_mul(v, gl_sub(v, 1));
+  gl_t b = gl_mul(gl_sub(v, 2), gl_sub(v, 3));
+  return gl_mul(a, b);
+}
+
+// W(c): wire column c of this row; LC(i): local constant i
+template <class WF, class CF>
+__device__ __forceinline__ void eval_gate(const GateDesc &g, WF W, CF LC, const gl_t *pih, Consumer &out) {
+  switch (g.kind) {
+  case G_NOOP:
+    break;
+  case G_CONSTANT:
+    for (uint32_t i = 0; i < g.p[0]; i++) out.emit(gl_sub(LC(i), W(i)));
+    break;
+  case G_PUBLIC_INPUT:
+    for (uint32_t i = 0; i < 4; i++) out.emit(gl_sub(W(i), pih[i]));
+    break;
+  case G_ARITHMETIC: {
+    const gl_t c0 = LC(0), c1 = LC(1);
+    for (uint32_t i = 0; i < g.p[0]; i++) {
+      gl_t m0 = W(4 * i), m1 = W(4 * i + 1), ad = W(4 * i + 2), o = W(4 * i + 3);
+      gl_t comp = gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(ad, c1));
+      out.emit(gl_sub(o, comp));
+    }
+    break;
+  }
+  case G_BASE_SUM: {
+    const uint32_t B = g.p[0], L = g.p[1];
+    gl_t acc = 0;
+    for (uint32_t i = L; i-- > 0;) acc = gl_add(gl_mul_small(acc, B), W(1 + i));
+    out.emit(gl_sub(acc, W(0)));
+    for (uint32_t i = 0; i < L; i++) out.emit(range_product(W(1 + i), B));
+    break;
+  }
+  case G_RANDOM_ACCESS: {
+    const uint32_t bits = g.p[0], copies = g.p[1], extra = g.p[2], vec = 1u << bits;
+    const uint32_t routed = (2 + vec) * copies + extra;
+    for (uint32_t c = 0; c < copies; c++) {
+      const uint32_t base = (2 + vec) * c, bw = routed + c * bits;
+      for (uint32_t b = 0; b < bits; b++) {
+        gl_t bv = W(bw + b);
+        out.emit(gl_mul(bv, gl_sub(bv, 1)));
+      }
+      gl_t rec = 0;
+      for (uint32_t b = bits; b-- > 0;) rec = gl_add(gl_dbl(rec), W(bw + b));
+      out.emit(gl_sub(rec, W(base)));
+      // fold the list: items[i] selected by the bits, lowest bit first
+      gl_t items[64];
+      for (uint32_t i = 0; i < vec; i++) items[i] = W(base + 2 + i);
+      uint32_t len = vec;
+      for (uint32_t b = 0; b < bits; b++) {
+        gl_t bv = W(bw + b);
+        for (uint32_t i = 0; i < len / 2; i++) {
+          gl_t x = items[2 * i], y = items[2 * i + 1];
+          items[i] = gl_add(x, gl_mul(bv, gl_sub(y, x)));
+        }
+        len >>= 1;
+      }
+      out.emit(gl_sub(items[0], W(base + 1)));
+    }
+    for (uint32_t i = 0; i < extra; i++) out.emit(gl_sub(LC(i), W((2 + vec) * copies + i)));
+    break;
+  }
+  case G_U32_ARITHMETIC: {
+    const uint32_t ops = g.p[0];
+    for (uint32_t i = 0; i < ops; i++) {
+      gl_t m0 = W(6 * i), m1 = W(6 * i + 1), ad = W(6 * i + 2);
+      gl_t lo = W(6 * i + 3), hi = W(6 * i + 4), inv = W(6 * i + 5);
+      gl_t computed = gl_add(gl_mul(m0, m1), ad);
+      gl_t diff = gl_sub(0xFFFFFFFFULL, hi);
+      gl_t hi_not_max = gl_sub(gl_mul(inv, diff), 1);
+      out.emit(gl_mul(hi_not_max, lo));
+      gl_t combined = gl_add(gl_mul(hi, 1ULL << 32), lo);
+      out.emit(gl_sub(combined, computed));
+      gl_t cl = 0, ch = 0;
+      for (uint32_t j = 32; j-- > 0;) {
+        gl_t limb = W(6 * ops + 32 * i + j);
+        out.emit(range4(limb));
+        if (j < 16) cl = gl_add(gl_mul_small(cl, 4), limb);
+        else ch = gl_add(gl_mul_small(ch, 4), limb);
+      }
+      out.emit(gl_sub(cl, lo));
+      out.emit(gl_sub(ch, hi));
+    }
+    break;
+  }
+  case G_U32_ADD_MANY: {
+    const uint32_t na = g.p[0], ops = g.p[1];
+    for (uint32_t i = 0; i < ops; i++) {
+      const uint32_t b = (na + 3) * i;
+      gl_t computed = 0;
+      for (uint32_t j = 0; j <= na; j++) computed = gl_add(computed, W(b + j));
+      gl_t res = W(b + na + 1), oc = W(b + na + 2);
+      gl_t combined = gl_add(gl_mul(oc, 1ULL << 32), res);
+      out.emit(gl_sub(combined, computed));
+      gl_t cr = 0, cc = 0;
+      for (uint32_t j = 18; j-- > 0;) {
+        gl_t limb = W((na + 3) * ops + 18 * i + j);
+        out.emit(range4(limb));
+        if (j < 16) cr = gl_add(gl_mul_small(cr, 4), limb);
+        else cc = gl_add(gl_mul_small(cc, 4), limb);
+      }
+      out.emit(gl_sub(cr, res));
+      out.emit(gl_sub(cc, oc));
+    }
+    break;
+  }
+  case G_U32_SUBTRACTION: {
+    const uint32_t ops = g.p[0];
+    for (uint32_t i = 0; i < ops; i++) {
+      gl_t x = W(5 * i), y = W(5 * i + 1), bin = W(5 * i + 2), res = W(5 * i + 3), bout = W(5 * i + 4);
+      gl_t init = gl_sub(gl_sub(x, y), bin);
+      out.emit(gl_sub(res, gl_add(init, gl_mul(bout, 1ULL << 32))));
+      gl_t comb = 0;
+      for (uint32_t j = 16; j-- > 0;) {
+        gl_t limb = W(5 * ops + 16 * i + j);
+        out.emit(range4(limb));
+        comb = gl_add(gl_mul_small(comb, 4), limb);
+      }
+      out.emit(gl_sub(comb, res));
+      out.emit(gl_mul(bout, gl_sub(1, bout)));
+    }
+    break;
+  }
+  case G_U32_RANGE_CHECK: {
+    const uint32_t nl = g.p[0];
+    for (uint32_t i = 0; i < nl; i++) {
+      gl_t sum = 0;
+      for (uint32_t j = 16; j-- > 0;) sum = gl_add(gl_mul_small(sum, 4), W(nl + 16 * i + j));
+      out.emit(gl_sub(sum, W(i)));
+      for (uint32_t j = 0; j < 16; j++) out.emit(range4(W(nl + 16 * i + j)));
+    }
+    break;
+  }
+  case G_COMPARISON: {
+    const uint32_t nb = g.p[0], nc = g.p[1], cb = (nb + nc - 1) / nc;
+    const uint32_t fc = 4, sc = 4 + nc, dm = 4 + 2 * nc, eq = 4 + 3 * nc, im = 4 + 4 * nc, msb = 4 + 5 * nc;
+    gl_t a = 0, b = 0;
+    for (uint32_t i = nc; i-- > 0;) {
+      a = gl_add(gl_mul_small(a, 1u << cb), W(fc + i));
+      b = gl_add(gl_mul_small(b, 1u << cb), W(sc + i));
+    }
+    out.emit(gl_sub(a, W(0)));
+    out.emit(gl_sub(b, W(1)));
+    gl_t msd_so_far = 0;
+    for (uint32_t i = 0; i < nc; i++) {
+      gl_t f = W(fc + i), s = W(sc + i);
+      out.emit(range_product(f, 1u << cb));
+      out.emit(range_product(s, 1u << cb));
+      gl_t diff = gl_sub(s, f);
+      gl_t e = W(eq + i), iv = W(im + i);
+      out.emit(gl_sub(gl_mul(diff, W(dm + i)), gl_sub(1, e)));
+      out.emit(gl_mul(e, diff));
+      out.emit(gl_sub(iv, gl_mul(e, msd_so_far)));
+      msd_so_far = gl_add(iv, gl_mul(gl_sub(1, e), diff));
+    }
+    gl_t msd = W(3);
+    out.emit(gl_sub(msd, msd_so_far));
+    gl_t bits = 0;
+    for (uint32_t i = 0; i < cb + 1; i++) {
+      gl_t bt = W(msb + i);
+      out.emit(gl_mul(bt, gl_sub(1, bt)));
+    }
+    for (uint32_t i = cb + 1; i-- > 0;) bits = gl_add(gl_dbl(bits), W(msb + i));
+    out.emit(gl_sub(gl_add(msd, 1ULL << cb), bits));
+    out.emit(gl_sub(W(2), W(msb + cb)));
+    break;
+  }
+  default:
+    break;
+  }
+}
+
+// grid: x = k blocks, y = coset
+__global__ __launch_bounds__(256) void quotient_kernel(QuotArgs a) {
+  const uint32_t n = 1u << a.d;
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t r = blockIdx.y;
+  if (k >= n) return;
+  const uint32_t ncs = a.NC + a.R, nzp = a.K * (1 + a.PP);
+  const gl_t *cs = a.cs_lde + (size_t)r * ncs * n + k;
+  const gl_t *wl = a.wires_lde + (size_t)r * a.W * n + k;
+  const gl_t *zl = a.zp_lde + (size_t)r * nzp * n;  // indexed with explicit k (next row)
+  const uint32_t kn = (k + 1) & (n - 1);
+  const gl_t x = gl_mul(a.coset_shift[r], root_pow(a.tw, a.tw_shift, a.d, k));
+  Consumer out;
+  out.acc0 = 0;
+  out.acc1 = 0;
+  out.ap0 = a.apow;
+  out.ap1 = a.apow + a.nterms;
+  out.t = 0;
+  // L_0(x) (Z_c(x) - 1),  L_0(x) = Z_H(x) / (n (x - 1))
+  const gl_t l0 = gl_mul(gl_mul(a.zh[r], a.n_inv), gl_inv(gl_sub(x, 1)));
+  for (uint32_t c = 0; c < a.K; c++) out.emit(gl_mul(l0, gl_sub(zl[(size_t)c * n + k], 1)));
+  // partial-product checks: prev * prod(num) - next * prod(den), chunk by chunk, both challenges
+  {
+    const gl_t bx0 = gl_mul(a.betas[0], x), bx1 = gl_mul(a.betas[1], x);
+    const uint32_t t_base = out.t;
+    for (uint32_t m = 0; m < a.nchunks; m++) {
+      gl_t n0 = 1, d0 = 1, n1 = 1, d1 = 1;
+      for (uint32_t j = m * a.QF; j < (m + 1) * a.QF && j < a.R; j++) {
+        const gl_t wv = wl[(size_t)j * n];
+        const gl_t sg = cs[(size_t)(a.NC + j) * n];
+        const gl_t kj = a.k_is[j];
+        n0 = gl_mul(n0, gl_add(gl_add(wv, gl_mul(bx0, kj)), a.gammas[0]));
+        d0 = gl_mul(d0, gl_add(gl_add(wv, gl_mul(a.betas[0], sg)), a.gammas[0]));
+        if (a.K > 1) {
+          n1 = gl_mul(n1, gl_add(gl_add(wv, gl_mul(bx1, kj)), a.gammas[1]));
+          d1 = gl_mul(d1, gl_add(gl_add(wv, gl_mul(a.betas[1], sg)), a.gammas[1]));
+        }
+      }
+      for (uint32_t c = 0; c < a.K; c++) {
+        const gl_t prev = m == 0 ? zl[(size_t)c * n + k] : zl[((size_t)a.K + c * a.PP + m - 1) * n + k];
+        const gl_t next = m == a.nchunks - 1 ? zl[(size_t)c * n + kn] : zl[((size_t)a.K + c * a.PP + m) * n + k];
+        const gl_t term = c == 0 ? gl_sub(gl_mul(prev, n0), gl_mul(next, d0)) : gl_sub(gl_mul(prev, n1), gl_mul(next, d1));
+        out.t = t_base + c * a.nchunks + m;
+        out.emit(term);
+      }
+    }
+    out.t = t_base + a.K * a.nchunks;
+  }
+  // gate constraints: every gate on every row, masked by its selector filter
+  const uint32_t t_gates = out.t;
+  gl_t tot0 = out.acc0, tot1 = out.acc1;
+  auto W = [&](uint32_t c) { return wl[(size_t)c * n]; };
+  auto LC = [&](uint32_t i) { return cs[(size_t)(a.num_selectors + i) * n]; };
+  for (uint32_t gi = 0; gi < a.num_gates; gi++) {
+    const GateDesc g = a.gates[gi];
+    if (g.num_constraints == 0) continue;
+    const gl_t s = cs[(size_t)g.sel_index * n];
+    gl_t f = 1;
+    for (uint32_t i = g.group_start; i < g.group_end; i++)
+      if (i != gi) f = gl_mul(f, gl_sub((gl_t)i, s));
+    if (a.num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFULL, s));
+    out.acc0 = 0;
+    out.acc1 = 0;
+    out.t = t_gates;
+    eval_gate(g, W, LC, a.pi_hash, out);
+    tot0 = gl_add(tot0, gl_mul(f, out.acc0));
+    tot1 = gl_add(tot1, gl_mul(f, out.acc1));
+  }
+  const gl_t zi = a.zh_inv[r];
+  a.out[((size_t)0 * (1u << a.rate_bits) + r) * n + k] = gl_mul(tot0, zi);
+  if (a.K > 1) a.out[((size_t)1 * (1u << a.rate_bits) + r) * n + k] = gl_mul(tot1, zi);
+}
+
+void quotient_eval(hipStream_t st, const QuotArgs &a) {
+  const uint32_t n = 1u << a.d;
+  const uint32_t threads = n >= 256 ? 256 : 64;
+  ProfScope ps("quotient_kernel", 8.0 * (double)n * (1u << a.rate_bits) * (a.NC + a.R + a.W + a.K * (1 + a.PP) + 2.0 * a.K));
+  hipLaunchKernelGGL(quotient_kernel, dim3((n + threads - 1) / threads, 1u << a.rate_bits), dim3(threads), 0, st, a);
+}
+
+// in [K][C][n]: coefficients (bit-reversed storage) of the per-coset interpolants
+// in the variable y = x / s_r; out [K*C][n]: chunk polynomials Q_m, m < C.
+__global__ __launch_bounds__(256) void quotient_chunks_kernel(const gl_t *in, const gl_t *inv_scale, gl_t *out,
+                                                             uint32_t d, uint32_t rate_bits, gl_t w_inv, gl_t gn_inv,
+                                                             gl_t rate_inv) {
+  const uint32_t n = 1u << d, C = 1u << rate_bits;
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = blockIdx.y;
+  if (p >= n) return;
+  gl_t P[8];
+  for (uint32_t r = 0; r < C; r++) P[r] = gl_mul(in[((size_t)c * C + r) * n + p], inv_scale[(size_t)r * n + p]);
+  gl_t wm = 1;       // w^-m
+  gl_t scale = rate_inv;  // (7^-n)^m / C
+  for (uint32_t m = 0; m < C; m++) {
+    gl_t acc = 0, wr = 1;  // w^(-r m)
+    for (uint32_t r = 0; r < C; r++) {
+      acc = gl_add(acc, gl_mul(P[r], wr));
+      wr = gl_mul(wr, wm);
+    }
+    out[((size_t)c * C + m) * n + p] = gl_mul(acc, scale);
+    wm = gl_mul(wm, w_inv);
+    scale = gl_mul(scale, gn_inv);
+  }
+}
+void quotient_chunks(hipStream_t st, const gl_t *in, const gl_t *inv_scale, gl_t *out, uint32_t d, uint32_t K,
+                     uint32_t rate_bits, gl_t w_inv, gl_t gn_inv, gl_t rate_inv) {
+  const uint32_t n = 1u << d;
+  const uint32_t threads = n >= 256 ? 256 : 64;
+  ProfScope ps("quotient_chunks_kernel", 8.0 * (double)n * (1u << rate_bits) * (2.0 * K + 1));
+  hipLaunchKernelGGL(quotient_chunks_kernel, dim3((n + threads - 1) / threads, K), dim3(threads), 0, st, in, inv_scale,
+                     out, d, rate_bits, w_inv, gn_inv, rate_inv);
+}
+
+}  // namespace p2

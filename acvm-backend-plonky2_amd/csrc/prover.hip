@@ -1,0 +1,1155 @@
+// prover.hip -- host pipeline + C ABI of libp2gpu.so (see include/p2gpu.h).
+//
+// Drop-in for the one call `circuit_data.prove(witnesses)` at
+// plonky2-backend/src/actions/prove_action.rs:96 (after witness generation):
+// plonky2 0.2.2 plonk/prover.rs prove_with_partition_witness restated as a
+// sequence of HIP kernel launches on one stream, with the Fiat-Shamir
+// transcript (iop/challenger.rs, Keccak duplex) run on the host between
+// phases -- each challenge needs only a 16 x 25 B Merkle cap or a few hundred
+// opening values back from the device.  Transcript order: SURVEY.md C.4.
+// The product path never touches oracle/; without a HIP device every entry
+// point fails with P2GPU_E_DEVICE.
+#include "internal.hpp"
+#include "../../include/p2gpu.h"
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace p2;
+
+namespace {
+
+thread_local std::string g_err;
+}  // namespace
+namespace p2 {
+thread_local Prof *g_prof = nullptr;
+}
+namespace {
+void set_err(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);      \
+      return P2GPU_E_DEVICE;                                                                   \
+    }                                                                                          \
+  } while (0)
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- host transcript (iop/challenger.rs, Challenger<F, KeccakHash<25>>) ----
+struct Challenger {
+  gl_t state[12];
+  gl_t in[8];
+  int n_in = 0;
+  gl_t out[8];
+  int n_out = 0;
+  Challenger() { memset(state, 0, sizeof state); }
+  void duplex() {
+    for (int i = 0; i < n_in; i++) state[i] = in[i];
+    n_in = 0;
+    keccak_permutation12(state);
+    for (int i = 0; i < 8; i++) out[i] = state[i];
+    n_out = 8;
+  }
+  void observe(gl_t e) {
+    n_out = 0;
+    in[n_in++] = e;
+    if (n_in == 8) duplex();
+  }
+  void observe_digest(const dig_t &d) {
+    gl_t e[4];
+    dig_to_elems(d, e);
+    for (int i = 0; i < 4; i++) observe(e[i]);
+  }
+  void observe_cap(const std::vector<dig_t> &cap) {
+    for (auto &d : cap) observe_digest(d);
+  }
+  void observe_ext(ext_t e) {
+    observe(e.c0);
+    observe(e.c1);
+  }
+  gl_t get() {
+    if (n_in != 0 || n_out == 0) duplex();
+    return out[--n_out];
+  }
+  ext_t get_ext() {
+    gl_t a = get();
+    gl_t b = get();
+    return ext_make(a, b);
+  }
+};
+
+dig_t host_hash_no_pad(const std::vector<gl_t> &v) {
+  uint64_t h[4];
+  keccak256_words(v.data(), v.size(), h);
+  return dig_from_state(h);
+}
+
+template <class T>
+struct DBuf {
+  T *p = nullptr;
+  size_t count = 0;
+  hipError_t alloc(size_t n) {
+    count = n;
+    if (n == 0) return hipSuccess;
+    return hipMalloc((void **)&p, n * sizeof(T));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  }
+};
+
+// one committed polynomial batch (plonky2 PolynomialBatch), GPU layout
+struct Batch {
+  uint32_t cols = 0, d = 0;
+  DBuf<gl_t> coeffs;  // [cols][n], bit-reversed positions
+  DBuf<gl_t> lde;     // [C][cols][n]
+  DBuf<dig_t> dig;    // all tree levels, level l at level_off[l], layout [C][n >> l]
+  std::vector<size_t> level_off;
+  std::vector<dig_t> cap;  // plonky2 order
+  void release() {
+    coeffs.release();
+    lde.release();
+    dig.release();
+  }
+};
+
+struct KernelStat {
+  double ms = 0, bytes = 0;
+  uint64_t launches = 0;
+};
+struct PendingEv {
+  const char *name;
+  double bytes;
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct p2gpu_circuit {
+  // parameters
+  uint32_t d, W, R, NC, num_selectors, K, QF, rate_bits, cap_h, pow_bits, num_queries, n_steps, arity[8];
+  uint32_t num_gates, num_pi, flags, PP, nchunks;
+  size_t n, N;
+  uint32_t C;  // cosets = 2^rate_bits
+  std::vector<GateDesc> gates;
+  std::vector<gl_t> k_is;
+  uint32_t nterms = 0, max_gate_constraints = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // tables
+  DBuf<gl_t> tw_fwd, tw_inv, scale, inv_scale, d_kis, d_sigmas, fri_scale;
+  DBuf<GateDesc> d_gates;
+  // oracles
+  Batch cs, wires, zp, quot;
+  dig_t circuit_digest;
+  // work buffers
+  DBuf<gl_t> wires_vals, zp_vals, cp, rowprod, scan_tmp, apow, qvals, qtmp, pw, partial, ext_apow, f01, f01v, fv;
+  std::vector<DBuf<gl_t>> fri_coef, fri_vals;
+  std::vector<Batch> fri_trees;  // only dig/level_off/cap used
+  DBuf<unsigned long long> pow_result;
+  DBuf<uint64_t> gather_ptrs;
+  DBuf<gl_t> gather_out;
+  size_t gather_cap = 0;
+  // knobs
+  uint64_t pow_hint = UINT64_MAX;
+  int profile = 0;
+  std::map<std::string, KernelStat> kstats;
+  std::vector<PendingEv> pending;
+  std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+struct EventProf : Prof {  // per-launch timing with HIP events on the launch stream
+  p2gpu_circuit *c;
+  hipEvent_t a = nullptr, b = nullptr;
+  const char *name = nullptr;
+  double bytes = 0;
+  explicit EventProf(p2gpu_circuit *c_) : c(c_) {}
+  hipEvent_t get() {
+    hipEvent_t e;
+    if (!c->event_pool.empty()) {
+      e = c->event_pool.back();
+      c->event_pool.pop_back();
+    } else {
+      (void)hipEventCreate(&e);
+    }
+    return e;
+  }
+  void begin(const char *k, double by) override {
+    name = k;
+    bytes = by;
+    a = get();
+    b = get();
+    (void)hipEventRecord(a, c->stream);
+  }
+  void end() override {
+    (void)hipEventRecord(b, c->stream);
+    c->pending.push_back({name, bytes, a, b});
+  }
+};
+void flush_kstats(p2gpu_circuit *c) {
+  for (auto &pe : c->pending) {
+    float ms = 0;
+    (void)hipEventSynchronize(pe.b);
+    (void)hipEventElapsedTime(&ms, pe.a, pe.b);
+    auto &s = c->kstats[pe.name];
+    s.ms += ms;
+    s.launches++;
+    s.bytes += pe.bytes;
+    c->event_pool.push_back(pe.a);
+    c->event_pool.push_back(pe.b);
+  }
+  c->pending.clear();
+}
+
+uint32_t brev(uint32_t x, unsigned bits) { return bitrev32(x, bits); }
+
+// allocate tree storage for [C][m0] leaf digests reduced to cap_per nodes per coset
+int tree_alloc(Batch &b, uint32_t C, size_t m0, size_t cap_per) {
+  b.level_off.clear();
+  size_t off = 0;
+  for (size_t m = m0;; m >>= 1) {
+    b.level_off.push_back(off);
+    off += C * m;
+    if (m <= cap_per) break;
+  }
+  HIP_TRY(b.dig.alloc(off));
+  return 0;
+}
+
+// build tree levels above the leaf digests and fetch the cap in plonky2 order
+int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
+  const uint32_t C = c->C;
+  size_t m = m0;
+  for (size_t l = 1; l < b.level_off.size(); l++) {
+    merkle_level(c->stream, b.dig.p + b.level_off[l - 1], b.dig.p + b.level_off[l], C, (uint32_t)m);
+    m >>= 1;
+  }
+  size_t cap_per = m;
+  std::vector<dig_t> raw(C * cap_per);
+  HIP_TRY(hipMemcpyAsync(raw.data(), b.dig.p + b.level_off.back(), raw.size() * sizeof(dig_t), hipMemcpyDeviceToHost,
+                         c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  unsigned lgC = c->rate_bits, lgp = 0;
+  while (((size_t)1 << lgp) < cap_per) lgp++;
+  b.cap.assign(C * cap_per, dig_t{});
+  for (uint32_t r = 0; r < C; r++)
+    for (uint32_t k = 0; k < cap_per; k++) b.cap[(size_t)brev(r, lgC) * cap_per + brev(k, lgp)] = raw[(size_t)r * cap_per + k];
+  return 0;
+}
+
+// coefficients (bit-reversed storage) -> LDE on the 2^rate_bits cosets -> leaf digests -> tree
+int batch_commit_from_coeffs(p2gpu_circuit *c, Batch &b) {
+  {
+    ntt_batch(c->stream, 1, b.coeffs.p, b.lde.p, c->d, b.cols, c->C, c->tw_fwd.p, 0, c->scale.p, 1, false);
+  }
+  {
+    hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, c->C, b.dig.p);
+  }
+  return tree_build(c, b, c->n);
+}
+int batch_commit_from_values(p2gpu_circuit *c, Batch &b, const gl_t *vals_dev) {
+  {
+    gl_t ninv = gl_inv((gl_t)c->n);
+    ntt_batch(c->stream, 0, vals_dev, b.coeffs.p, c->d, b.cols, 1, c->tw_inv.p, 0, nullptr, ninv, false);
+  }
+  return batch_commit_from_coeffs(c, b);
+}
+int batch_alloc(p2gpu_circuit *c, Batch &b, uint32_t cols) {
+  b.cols = cols;
+  b.d = c->d;
+  HIP_TRY(b.coeffs.alloc((size_t)cols * c->n));
+  HIP_TRY(b.lde.alloc((size_t)cols * c->N));
+  size_t cap_per = ((size_t)1 << c->cap_h) >> c->rate_bits;
+  return tree_alloc(b, c->C, c->n, cap_per);
+}
+
+struct Buf {
+  std::vector<uint8_t> v;
+  void put(const void *p, size_t n) {
+    const uint8_t *q = (const uint8_t *)p;
+    v.insert(v.end(), q, q + n);
+  }
+  void u64(uint64_t x) { put(&x, 8); }
+  void ext(ext_t e) {
+    u64(e.c0);
+    u64(e.c1);
+  }
+  void dig(const dig_t &d) { put(d.w, 25); }
+};
+
+// sibling positions (within the digest buffer of a tree) for leaf index `j`
+// (plonky2 order) of a tree over [C][m0] leaf digests
+void path_positions(const Batch &b, uint32_t C, unsigned lgC, size_t m0, unsigned lgm0, size_t j,
+                    std::vector<size_t> &pos) {
+  uint32_t r = brev((uint32_t)(j >> lgm0), lgC);
+  uint32_t k = brev((uint32_t)(j & (m0 - 1)), lgm0);
+  size_t m = m0;
+  for (size_t l = 0; l + 1 < b.level_off.size(); l++) {
+    size_t kk = k & (m - 1);
+    size_t sib = kk ^ (m >> 1);
+    pos.push_back(b.level_off[l] + (size_t)r * m + sib);
+    m >>= 1;
+  }
+  (void)C;
+}
+
+int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
+               size_t *proof_len, p2gpu_timings *tm, double h2d_ms) {
+  if (n_pi != c->num_pi || n_pi != 0) {
+    set_err("public inputs are not supported yet (needs PoseidonGate); got n_pi=%u, circuit has %u", n_pi, c->num_pi);
+    return P2GPU_E_ARG;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const uint32_t d = c->d, K = c->K, R = c->R, W = c->W, NC = c->NC, QF = c->QF, PP = c->PP, C = c->C;
+  const size_t n = c->n, N = c->N;
+  const uint32_t ncs = NC + R, nzp = K * (1 + PP), nq = K * QF;
+  const uint32_t nall = ncs + W + nzp + nq;
+  EventProf prof(c);
+  struct ProfGuard {
+    ProfGuard(Prof *p) { g_prof = p; }
+    ~ProfGuard() { g_prof = nullptr; }
+  } prof_guard(c->profile ? &prof : nullptr);
+  double t0 = now_ms(), t1;
+  p2gpu_timings T;
+  memset(&T, 0, sizeof T);
+  T.h2d_ms = h2d_ms;
+
+  gl_t pih[4] = {0, 0, 0, 0};  // InnerHasher(Poseidon).hash_no_pad([]) = 0^4
+
+  // ---- 1. wires commitment ----
+  if (int rc = batch_commit_from_values(c, c->wires, wires_dev)) return rc;
+  Challenger ch;
+  ch.observe_digest(c->circuit_digest);
+  for (int i = 0; i < 4; i++) ch.observe(pih[i]);
+  ch.observe_cap(c->wires.cap);
+  gl_t betas[2] = {0, 0}, gammas[2] = {0, 0}, alphas[2] = {0, 0};
+  for (uint32_t k = 0; k < K; k++) betas[k] = ch.get();
+  for (uint32_t k = 0; k < K; k++) gammas[k] = ch.get();
+  t1 = now_ms();
+  T.wires_commit_ms = t1 - t0;
+
+  // ---- 2. partial products and Z ----
+  {
+    ZsArgs a;
+    a.wires = wires_dev;
+    a.sigmas = c->d_sigmas.p;
+    a.k_is = c->d_kis.p;
+    a.sub_tw = c->tw_fwd.p;
+    a.tw_shift = 0;
+    a.d = d; a.R = R; a.QF = QF; a.nchunks = c->nchunks; a.K = K;
+    for (uint32_t k = 0; k < 2; k++) { a.betas[k] = betas[k]; a.gammas[k] = gammas[k]; }
+    a.cp = c->cp.p;
+    a.rowprod = c->rowprod.p;
+    a.zp = c->zp_vals.p;
+    zs_partial_products(st, a, c->scan_tmp.p);
+  }
+  if (int rc = batch_commit_from_values(c, c->zp, c->zp_vals.p)) return rc;
+  ch.observe_cap(c->zp.cap);
+  for (uint32_t k = 0; k < K; k++) alphas[k] = ch.get();
+  t0 = now_ms();
+  T.zs_commit_ms = t0 - t1;
+
+  // ---- 3. quotient ----
+  {
+    const uint32_t nterms = c->nterms;
+    std::vector<gl_t> ap((size_t)2 * nterms, 0);
+    for (uint32_t k = 0; k < K; k++) {
+      gl_t a = 1;
+      for (uint32_t t = 0; t < nterms; t++) {
+        ap[(size_t)k * nterms + t] = a;
+        a = gl_mul(a, alphas[k]);
+      }
+    }
+    HIP_TRY(hipMemcpyAsync(c->apow.p, ap.data(), ap.size() * 8, hipMemcpyHostToDevice, st));
+    QuotArgs q;
+    memset(&q, 0, sizeof q);
+    q.cs_lde = c->cs.lde.p;
+    q.wires_lde = c->wires.lde.p;
+    q.zp_lde = c->zp.lde.p;
+    q.k_is = c->d_kis.p;
+    q.tw = c->tw_fwd.p;
+    q.apow = c->apow.p;
+    q.gates = c->d_gates.p;
+    q.out = c->qvals.p;
+    q.tw_shift = 0; q.d = d; q.rate_bits = c->rate_bits; q.W = W; q.R = R; q.NC = NC;
+    q.num_selectors = c->num_selectors; q.K = K; q.QF = QF; q.nchunks = c->nchunks; q.PP = PP;
+    q.num_gates = c->num_gates; q.nterms = nterms;
+    for (uint32_t k = 0; k < 2; k++) { q.betas[k] = betas[k]; q.gammas[k] = gammas[k]; }
+    for (int i = 0; i < 4; i++) q.pi_hash[i] = pih[i];
+    gl_t wN = gl_root(d + c->rate_bits), wC = gl_root(c->rate_bits), gn = gl_pow(GL_GEN, n);
+    for (uint32_t r = 0; r < C; r++) {
+      q.coset_shift[r] = gl_mul(GL_GEN, gl_pow(wN, r));
+      q.zh[r] = gl_sub(gl_mul(gn, gl_pow(wC, r)), 1);
+      q.zh_inv[r] = gl_inv(q.zh[r]);
+    }
+    q.n_inv = gl_inv((gl_t)n);
+    {
+      quotient_eval(st, q);
+    }
+    // coset_ifft of size N = per-coset inverse transforms + cross-coset butterflies
+    {
+      ntt_batch(st, 0, c->qvals.p, c->qtmp.p, d, K * C, 1, c->tw_inv.p, 0, nullptr, q.n_inv, false);
+    }
+    {
+      quotient_chunks(st, c->qtmp.p, c->inv_scale.p, c->quot.coeffs.p, d, K, c->rate_bits, gl_inv(wC), gl_inv(gn),
+                      gl_inv((gl_t)C));
+    }
+  }
+  if (int rc = batch_commit_from_coeffs(c, c->quot)) return rc;
+  ch.observe_cap(c->quot.cap);
+  ext_t zeta = ch.get_ext();
+  t1 = now_ms();
+  T.quotient_ms = t1 - t0;
+  {
+    ext_t zn = zeta;
+    for (uint32_t i = 0; i < d; i++) zn = ext_mul(zn, zn);
+    if (ext_eq(zn, ext_from(1))) {
+      set_err("Opening point is in the subgroup.");
+      return P2GPU_E_OPENING_IN_SUBGROUP;
+    }
+  }
+
+  // ---- 4. openings ----
+  const ext_t gzeta = ext_scale(zeta, gl_root(d));
+  Batch *oracles[4] = {&c->cs, &c->wires, &c->zp, &c->quot};
+  std::vector<ext_t> op(nall + K);
+  {
+    uint32_t parts = 1;
+    while (parts < 16 && (n / (parts * 2)) >= 1024) parts *= 2;
+    ext_powers_bitrev(st, zeta, d, c->pw.p);
+    ext_powers_bitrev(st, gzeta, d, c->pw.p + 2 * n);
+    size_t base = 0;
+    for (int o = 0; o < 4; o++) {
+      eval_columns(st, oracles[o]->coeffs.p, oracles[o]->cols, d, c->pw.p, parts, c->partial.p + base * parts * 2);
+      base += oracles[o]->cols;
+    }
+    {
+      eval_columns(st, c->zp.coeffs.p, K, d, c->pw.p + 2 * n, parts, c->partial.p + base * parts * 2);
+    }
+    std::vector<gl_t> part((size_t)(nall + K) * parts * 2);
+    HIP_TRY(hipMemcpyAsync(part.data(), c->partial.p, part.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t j = 0; j < nall + K; j++) {
+      gl_t a0 = 0, a1 = 0;
+      for (uint32_t p = 0; p < parts; p++) {
+        a0 = gl_add(a0, part[(j * parts + p) * 2]);
+        a1 = gl_add(a1, part[(j * parts + p) * 2 + 1]);
+      }
+      op[j] = ext_make(a0, a1);
+    }
+  }
+  for (size_t j = 0; j < nall + K; j++) ch.observe_ext(op[j]);
+  t0 = now_ms();
+  T.openings_ms = t0 - t1;
+
+  // ---- 5. FRI ----
+  const ext_t alpha = ch.get_ext();
+  {
+    std::vector<gl_t> apw((size_t)2 * nall);
+    ext_t a = ext_from(1);
+    ext_t f0z = ext_from(0), f1z = ext_from(0);
+    for (uint32_t j = 0; j < nall; j++) {
+      apw[2 * j] = a.c0;
+      apw[2 * j + 1] = a.c1;
+      f0z = ext_add(f0z, ext_mul(a, op[j]));
+      if (j < K) f1z = ext_add(f1z, ext_mul(a, op[nall + j]));
+      a = ext_mul(a, alpha);
+    }
+    HIP_TRY(hipMemcpyAsync(c->ext_apow.p, apw.data(), apw.size() * 8, hipMemcpyHostToDevice, st));
+    gl_t *F0 = c->f01.p, *F1 = c->f01.p + 2 * n;
+    uint32_t j0 = 0;
+    for (int o = 0; o < 4; o++) {
+      reduce_columns(st, oracles[o]->coeffs.p, oracles[o]->cols, d, c->ext_apow.p, j0, F0, o != 0);
+      j0 += oracles[o]->cols;
+    }
+    {
+      reduce_columns(st, c->zp.coeffs.p, K, d, c->ext_apow.p, 0, F1, false);
+    }
+    {
+      ntt_batch(st, 1, c->f01.p, c->f01v.p, d, 4, 1, c->tw_fwd.p, 0, nullptr, 1, false);
+    }
+    fri_quotient_values(st, c->f01v.p, c->f01v.p + 2 * n, d, c->tw_fwd.p, 0, zeta, gzeta, f0z, f1z, ext_pow(alpha, K),
+                        c->fv.p);
+    {
+      ntt_batch(st, 0, c->fv.p, c->fri_coef[0].p, d, 2, 1, c->tw_inv.p, 0, nullptr, gl_inv((gl_t)n), false);
+    }
+    {
+      ntt_batch(st, 1, c->fri_coef[0].p, c->fri_vals[0].p, d, 2, C, c->tw_fwd.p, 0, c->scale.p, 1, false);
+    }
+  }
+  std::vector<ext_t> fri_betas;
+  uint32_t ds = d;
+  gl_t shift = GL_GEN;
+  for (uint32_t s = 0; s < c->n_steps; s++) {
+    const uint32_t ab = c->arity[s];
+    Batch &tr = c->fri_trees[s];
+    {
+      hash_fri_leaves(st, c->fri_vals[s].p, ds, C, ab, tr.dig.p);
+    }
+    if (int rc = tree_build(c, tr, ((size_t)1 << ds) >> ab)) return rc;
+    ch.observe_cap(tr.cap);
+    ext_t beta = ch.get_ext();
+    fri_betas.push_back(beta);
+    fri_fold(st, c->fri_coef[s].p, ds, ab, beta, c->fri_coef[s + 1].p);
+    for (uint32_t q = 0; q < ab; q++) shift = gl_sqr(shift);
+    ds -= ab;
+    if (s + 1 < c->n_steps) {
+      fill_coset_scale(st, c->fri_scale.p, shift, gl_root(ds + c->rate_bits), ds, C, 1);
+      ntt_batch(st, 1, c->fri_coef[s + 1].p, c->fri_vals[s + 1].p, ds, 2, C, c->tw_fwd.p, d - ds, c->fri_scale.p, 1,
+                false);
+    }
+  }
+  const size_t n_final = (size_t)1 << ds;
+  std::vector<ext_t> final_poly(n_final);
+  {
+    std::vector<gl_t> raw(2 * n_final);
+    HIP_TRY(hipMemcpyAsync(raw.data(), c->fri_coef[c->n_steps].p, raw.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t j = 0; j < n_final; j++) {
+      size_t p = brev((uint32_t)j, ds);
+      final_poly[j] = ext_make(raw[p], raw[n_final + p]);
+    }
+  }
+  for (auto &e : final_poly) ch.observe_ext(e);
+
+  // PoW: minimum-witness policy (upstream's parallel find_any is not deterministic)
+  uint64_t pow_witness = c->pow_hint;
+  if (pow_witness == UINT64_MAX) {
+    gl_t inter[12];
+    memcpy(inter, ch.state, sizeof inter);
+    for (int i = 0; i < ch.n_in; i++) inter[i] = ch.in[i];
+    const uint64_t batch = 1ull << 20;
+    for (uint64_t base = 0;; base += batch) {
+      unsigned long long init = ~0ull;
+      HIP_TRY(hipMemcpyAsync(c->pow_result.p, &init, 8, hipMemcpyHostToDevice, st));
+      {
+        pow_search(st, inter, (uint32_t)ch.n_in, c->pow_bits, base, batch, c->pow_result.p);
+      }
+      unsigned long long res;
+      HIP_TRY(hipMemcpyAsync(&res, c->pow_result.p, 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (res != ~0ull) {
+        pow_witness = res;
+        break;
+      }
+      if (base > (1ull << 40)) {
+        set_err("proof of work failed");
+        return P2GPU_E_DEVICE;
+      }
+    }
+  }
+  ch.observe(pow_witness);
+  gl_t pow_resp = ch.get();
+  if (c->pow_bits && (pow_resp >> (64 - c->pow_bits)) != 0) {
+    set_err("proof-of-work witness does not satisfy the leading-zero check");
+    return P2GPU_E_ARG;
+  }
+  T.pow_witness = pow_witness;
+  std::vector<size_t> qidx(c->num_queries);
+  for (auto &x : qidx) x = (size_t)(ch.get() % N);
+
+  // ---- query gather: one launch, one D2H ----
+  const unsigned lgC = c->rate_bits;
+  std::vector<uint64_t> ptrs;
+  ptrs.reserve(c->gather_cap);
+  auto push_dig = [&](const Batch &b, size_t pos) {
+    const uint64_t base = (uint64_t)(uintptr_t)(b.dig.p + pos);
+    for (int w = 0; w < 4; w++) ptrs.push_back(base + 8 * w);
+  };
+  std::vector<size_t> pos;
+  for (size_t x : qidx) {
+    for (int o = 0; o < 4; o++) {
+      const Batch &b = *oracles[o];
+      uint32_t r = brev((uint32_t)(x >> d), lgC), k = brev((uint32_t)(x & (n - 1)), d);
+      for (uint32_t col = 0; col < b.cols; col++)
+        ptrs.push_back((uint64_t)(uintptr_t)(b.lde.p + ((size_t)r * b.cols + col) * n + k));
+      pos.clear();
+      path_positions(b, C, lgC, n, d, x, pos);
+      for (size_t p : pos) push_dig(b, p);
+    }
+    size_t xi = x;
+    uint32_t dcur = d;
+    for (uint32_t s = 0; s < c->n_steps; s++) {
+      const uint32_t ab = c->arity[s];
+      const size_t npc = (size_t)1 << dcur, per = npc >> ab;  // per-coset leaves
+      const size_t li = xi >> ab;                              // leaf index (plonky2 order) in tree s
+      const unsigned lgper = dcur - ab;
+      uint32_t r = brev((uint32_t)(li >> lgper), lgC), kl = brev((uint32_t)(li & (per - 1)), lgper);
+      const gl_t *v0 = c->fri_vals[s].p + (size_t)r * 2 * npc;
+      for (uint32_t t = 0; t < (1u << ab); t++) {
+        size_t k = (size_t)brev(t, ab) * per + kl;
+        ptrs.push_back((uint64_t)(uintptr_t)(v0 + k));
+        ptrs.push_back((uint64_t)(uintptr_t)(v0 + npc + k));
+      }
+      pos.clear();
+      path_positions(c->fri_trees[s], C, lgC, per, lgper, li, pos);
+      for (size_t p : pos) push_dig(c->fri_trees[s], p);
+      xi = li;
+      dcur -= ab;
+    }
+  }
+  if (ptrs.size() > c->gather_cap) {
+    set_err("internal: gather buffer too small");
+    return P2GPU_E_DEVICE;
+  }
+  std::vector<gl_t> gathered(ptrs.size());
+  HIP_TRY(hipMemcpyAsync(c->gather_ptrs.p, ptrs.data(), ptrs.size() * 8, hipMemcpyHostToDevice, st));
+  {
+    gather_u64(st, c->gather_ptrs.p, (uint32_t)ptrs.size(), c->gather_out.p);
+  }
+  HIP_TRY(hipMemcpyAsync(gathered.data(), c->gather_out.p, ptrs.size() * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+
+  // ---- serialise: plonky2 ProofWithPublicInputs::to_bytes ----
+  Buf out;
+  out.v.reserve(p2gpu_proof_size_bound(c));
+  for (auto &dg : c->wires.cap) out.dig(dg);
+  for (auto &dg : c->zp.cap) out.dig(dg);
+  for (auto &dg : c->quot.cap) out.dig(dg);
+  // OpeningSet: constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys
+  for (size_t j = 0; j < ncs + W + K; j++) out.ext(op[j]);
+  for (size_t k = 0; k < K; k++) out.ext(op[nall + k]);
+  for (size_t j = ncs + W + K; j < nall; j++) out.ext(op[j]);
+  for (uint32_t s = 0; s < c->n_steps; s++)
+    for (auto &dg : c->fri_trees[s].cap) out.dig(dg);
+  {
+    size_t g = 0;
+    auto put_path = [&](size_t nsib) {
+      uint8_t l = (uint8_t)nsib;
+      out.put(&l, 1);
+      for (size_t i = 0; i < nsib; i++) {
+        dig_t dg;
+        for (int w = 0; w < 4; w++) dg.w[w] = gathered[g++];
+        out.dig(dg);
+      }
+    };
+    for (size_t qi = 0; qi < qidx.size(); qi++) {
+      for (int o = 0; o < 4; o++) {
+        const Batch &b = *oracles[o];
+        out.put(&gathered[g], 8 * (size_t)b.cols);
+        g += b.cols;
+        put_path(b.level_off.size() - 1);
+      }
+      for (uint32_t s = 0; s < c->n_steps; s++) {
+        size_t words = 2u << c->arity[s];
+        out.put(&gathered[g], 8 * words);
+        g += words;
+        put_path(c->fri_trees[s].level_off.size() - 1);
+      }
+    }
+  }
+  for (auto &e : final_poly) out.ext(e);
+  out.u64(pow_witness);
+  for (uint32_t i = 0; i < n_pi; i++) out.u64(pis[i]);
+  t1 = now_ms();
+  T.fri_ms = t1 - t0;
+  T.total_ms = T.wires_commit_ms + T.zs_commit_ms + T.quotient_ms + T.openings_ms + T.fri_ms;
+  if (c->profile) flush_kstats(c);
+  if (tm) *tm = T;
+  if (out.v.size() > *proof_len) {
+    *proof_len = out.v.size();
+    set_err("proof buffer too small: need %zu bytes", out.v.size());
+    return P2GPU_E_BUFFER;
+  }
+  memcpy(proof_out, out.v.data(), out.v.size());
+  *proof_len = out.v.size();
+  return P2GPU_OK;
+}
+
+void circuit_release(p2gpu_circuit *c) {
+  c->tw_fwd.release(); c->tw_inv.release(); c->scale.release(); c->inv_scale.release(); c->d_kis.release();
+  c->d_sigmas.release(); c->fri_scale.release(); c->d_gates.release();
+  c->cs.release(); c->wires.release(); c->zp.release(); c->quot.release();
+  c->wires_vals.release(); c->zp_vals.release(); c->cp.release(); c->rowprod.release(); c->scan_tmp.release();
+  c->apow.release(); c->qvals.release(); c->qtmp.release(); c->pw.release(); c->partial.release();
+  c->ext_apow.release(); c->f01.release(); c->f01v.release(); c->fv.release();
+  for (auto &b : c->fri_coef) b.release();
+  for (auto &b : c->fri_vals) b.release();
+  for (auto &b : c->fri_trees) b.release();
+  c->pow_result.release(); c->gather_ptrs.release(); c->gather_out.release();
+  for (auto e : c->event_pool) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+int g_device = -1;
+
+int ensure_device() {
+  if (g_device >= 0) return 0;
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt == 0) {
+    set_err("no HIP device available (%s); libp2gpu has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    return P2GPU_E_DEVICE;
+  }
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  g_device = dev;
+  return 0;
+}
+
+uint32_t gate_num_constraints(uint32_t kind, const uint32_t p[4]) {
+  switch (kind) {
+  case G_NOOP: return 0;
+  case G_CONSTANT: return p[0];
+  case G_PUBLIC_INPUT: return 4;
+  case G_ARITHMETIC: return p[0];
+  case G_BASE_SUM: return 1 + p[1];
+  case G_RANDOM_ACCESS: return p[1] * (p[0] + 2) + p[2];
+  case G_U32_ARITHMETIC: return p[0] * 36;
+  case G_U32_ADD_MANY: return p[1] * 21;
+  case G_U32_SUBTRACTION: return p[0] * 19;
+  case G_U32_RANGE_CHECK: return p[0] * 17;
+  case G_COMPARISON: return 6 + 5 * p[1] + (p[0] + p[1] - 1) / p[1];
+  }
+  return 0;
+}
+
+}  // namespace
+
+// scratch allocations of the stage-level operators
+namespace {
+struct Scratch {
+  std::vector<void *> ptrs;
+  hipStream_t st = nullptr;
+  ~Scratch() {
+    for (void *p : ptrs) (void)hipFree(p);
+    if (st) (void)hipStreamDestroy(st);
+  }
+  template <class T> T *alloc(size_t n) {
+    void *p = nullptr;
+    if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    return (T *)p;
+  }
+};
+}  // namespace
+
+
+extern "C" {
+
+const char *p2gpu_last_error(void) { return g_err.c_str(); }
+
+int p2gpu_init(const int *device_ids, int n_devices) {
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt == 0) {
+    set_err("no HIP device available (%s); libp2gpu has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    return P2GPU_E_DEVICE;
+  }
+  int dev = (device_ids && n_devices > 0) ? device_ids[0] : 0;
+  if (dev < 0 || dev >= cnt) {
+    set_err("device id %d out of range (%d devices)", dev, cnt);
+    return P2GPU_E_ARG;
+  }
+  HIP_TRY(hipSetDevice(dev));
+  g_device = dev;
+  return P2GPU_OK;
+}
+
+int p2gpu_device_info(char *name_out, size_t name_cap, int *cu_count, size_t *hbm_bytes) {
+  if (int rc = ensure_device()) return rc;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+  if (name_out && name_cap) snprintf(name_out, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  return P2GPU_OK;
+}
+
+size_t p2gpu_proof_size_bound(const p2gpu_circuit *c) {
+  const size_t ncap = (size_t)1 << c->cap_h;
+  const size_t ncs = c->NC + c->R, nzp = c->K * (1 + c->PP), nq = c->K * c->QF;
+  size_t sz = 3 * ncap * 25 + 16 * (ncs + c->W + nzp + nq + c->K) + c->n_steps * ncap * 25;
+  size_t per_q = 8 * (ncs + c->W + nzp + nq) + 4 * (1 + 25 * (size_t)(c->d + c->rate_bits));
+  for (uint32_t s = 0; s < c->n_steps; s++) per_q += (16u << c->arity[s]) + 1 + 25 * (size_t)(c->d + c->rate_bits);
+  sz += per_q * c->num_queries + 16 * c->n + 8 + 8 * c->num_pi + 64;
+  return sz;
+}
+
+int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c) {
+  if (!blob || !out_c) return P2GPU_E_ARG;
+  if (int rc = ensure_device()) return rc;
+  if (len < 256) { set_err("blob too short"); return P2GPU_E_BLOB; }
+  uint32_t h[64];
+  memcpy(h, blob, sizeof h);
+  if (h[0] != 0x43473250u || h[1] != 1) { set_err("bad blob magic/version"); return P2GPU_E_BLOB; }
+  p2gpu_circuit *c = new p2gpu_circuit();
+  c->d = h[2]; c->W = h[3]; c->R = h[4]; c->NC = h[5]; c->num_selectors = h[6]; c->K = h[7]; c->QF = h[8];
+  c->rate_bits = h[9]; c->cap_h = h[10]; c->pow_bits = h[11]; c->num_queries = h[12]; c->n_steps = h[13];
+  for (int i = 0; i < 8; i++) c->arity[i] = h[14 + i];
+  uint32_t hasher = h[22];
+  c->num_gates = h[23]; c->num_pi = h[24]; c->flags = h[25]; c->PP = h[26];
+  c->n = (size_t)1 << c->d;
+  c->N = c->n << c->rate_bits;
+  c->C = 1u << c->rate_bits;
+  c->nchunks = (c->R + c->QF - 1) / c->QF;
+  c->device = g_device;
+  auto fail = [&](int rc, const char *msg) {
+    set_err("%s", msg);
+    circuit_release(c);
+    delete c;
+    return rc;
+  };
+  if (hasher != 0) return fail(P2GPU_E_BLOB, "unsupported hasher (only KeccakHash<25>)");
+  if (c->d < 1 || c->d > 24 || c->K < 1 || c->K > 2 || c->rate_bits < 1 || c->rate_bits > 3 || c->cap_h < c->rate_bits ||
+      c->cap_h > c->rate_bits + c->d || c->n_steps > 8 || c->R > MAX_ROUTED || c->nchunks > 16 || c->PP != c->nchunks - 1 ||
+      c->num_gates > MAX_GATES || c->num_queries > 64 || c->W < c->R || (1u << c->rate_bits) != c->QF)
+    return fail(P2GPU_E_BLOB, "unsupported circuit parameters");
+  size_t off = 256;
+  if (len < off + (size_t)c->num_gates * 48) return fail(P2GPU_E_BLOB, "blob truncated (gate table)");
+  c->max_gate_constraints = 0;
+  for (uint32_t i = 0; i < c->num_gates; i++) {
+    uint32_t g[12];
+    memcpy(g, blob + off, sizeof g);
+    off += sizeof g;
+    GateDesc G;
+    G.kind = g[0];
+    memcpy(G.p, &g[1], 16);
+    G.sel_index = g[5]; G.group_start = g[6]; G.group_end = g[7]; G.num_constraints = g[8]; G.degree = g[9];
+    G.num_constants = g[10]; G.pad = 0;
+    if (G.kind >= G_KIND_COUNT || G.kind == G_POSEIDON) return fail(P2GPU_E_BLOB, "unsupported gate kind in blob");
+    if (G.num_constraints != gate_num_constraints(G.kind, G.p)) return fail(P2GPU_E_BLOB, "gate constraint count mismatch");
+    if (G.kind == G_RANDOM_ACCESS && G.p[0] > 6) return fail(P2GPU_E_BLOB, "RandomAccessGate bits > 6 unsupported");
+    if (G.sel_index >= c->num_selectors || G.group_end > c->num_gates) return fail(P2GPU_E_BLOB, "bad selector info");
+    c->max_gate_constraints = std::max(c->max_gate_constraints, G.num_constraints);
+    c->gates.push_back(G);
+  }
+  c->nterms = c->K + c->K * c->nchunks + c->max_gate_constraints;
+  const uint8_t *cap_in = nullptr;
+  if (c->flags & 2) {
+    cap_in = blob + off;
+    off += (size_t)32 << c->cap_h;
+  }
+  const size_t n = c->n;
+  size_t need = off + 8 * ((size_t)c->R + (size_t)c->NC * n + (size_t)c->R * n);
+  if (len < need) return fail(P2GPU_E_BLOB, "blob truncated (tables)");
+  const gl_t *k_is = (const gl_t *)(blob + off);
+  off += 8 * (size_t)c->R;
+  const gl_t *constants = (const gl_t *)(blob + off);
+  off += 8 * (size_t)c->NC * n;
+  const gl_t *sigmas = (const gl_t *)(blob + off);
+  c->k_is.assign(k_is, k_is + c->R);
+
+  // ---- device state ----
+  auto H = [&](hipError_t e, const char *what) -> int {
+    if (e == hipSuccess) return 0;
+    set_err("%s: %s", what, hipGetErrorString(e));
+    return P2GPU_E_DEVICE;
+  };
+#define CK(e, what)                                   \
+  if (H((e), what)) {                                 \
+    std::string keep = g_err;                         \
+    circuit_release(c);                               \
+    delete c;                                         \
+    g_err = keep;                                     \
+    return P2GPU_E_DEVICE;                            \
+  }
+  CK(hipSetDevice(c->device), "hipSetDevice");
+  CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+  hipStream_t st = c->stream;
+  const uint32_t d = c->d, K = c->K, C = c->C;
+  const uint32_t ncs = c->NC + c->R, nzp = K * (1 + c->PP), nq = K * c->QF;
+  const uint32_t nall = ncs + c->W + nzp + nq;
+  const size_t half = n >= 2 ? n / 2 : 1;
+  CK(c->tw_fwd.alloc(half), "alloc tw");
+  CK(c->tw_inv.alloc(half), "alloc tw");
+  CK(c->scale.alloc((size_t)C * n), "alloc scale");
+  CK(c->inv_scale.alloc((size_t)C * n), "alloc scale");
+  CK(c->fri_scale.alloc((size_t)C * n), "alloc scale");
+  CK(c->d_kis.alloc(c->R), "alloc kis");
+  CK(c->d_sigmas.alloc((size_t)c->R * n), "alloc sigmas");
+  CK(c->d_gates.alloc(c->num_gates ? c->num_gates : 1), "alloc gates");
+  gl_t wn = gl_root(d), wN = gl_root(d + c->rate_bits);
+  fill_powers(st, c->tw_fwd.p, wn, (uint32_t)half);
+  fill_powers(st, c->tw_inv.p, gl_inv(wn), (uint32_t)half);
+  fill_coset_scale(st, c->scale.p, GL_GEN, wN, d, C, 1);
+  fill_coset_scale(st, c->inv_scale.p, gl_inv(GL_GEN), gl_inv(wN), d, C, 1);
+  CK(hipMemcpyAsync(c->d_kis.p, k_is, 8 * (size_t)c->R, hipMemcpyHostToDevice, st), "copy kis");
+  CK(hipMemcpyAsync(c->d_sigmas.p, sigmas, 8 * (size_t)c->R * n, hipMemcpyHostToDevice, st), "copy sigmas");
+  if (c->num_gates)
+    CK(hipMemcpyAsync(c->d_gates.p, c->gates.data(), sizeof(GateDesc) * c->num_gates, hipMemcpyHostToDevice, st), "copy gates");
+  if (batch_alloc(c, c->cs, ncs) || batch_alloc(c, c->wires, c->W) || batch_alloc(c, c->zp, nzp) || batch_alloc(c, c->quot, nq)) {
+    std::string keep = g_err;
+    circuit_release(c);
+    delete c;
+    g_err = keep;
+    return P2GPU_E_DEVICE;
+  }
+  CK(c->wires_vals.alloc((size_t)c->W * n), "alloc wires");
+  CK(c->zp_vals.alloc((size_t)nzp * n), "alloc zp");
+  CK(c->cp.alloc((size_t)K * c->nchunks * n), "alloc cp");
+  CK(c->rowprod.alloc((size_t)K * n), "alloc rowprod");
+  CK(c->scan_tmp.alloc((size_t)K * (n + (n + 255) / 256 + 8)), "alloc scan");
+  CK(c->apow.alloc((size_t)2 * c->nterms), "alloc apow");
+  CK(c->qvals.alloc((size_t)K * C * n), "alloc qvals");
+  CK(c->qtmp.alloc((size_t)K * C * n), "alloc qtmp");
+  CK(c->pw.alloc((size_t)4 * n), "alloc pw");
+  CK(c->partial.alloc((size_t)(nall + K) * 16 * 2), "alloc partial");
+  CK(c->ext_apow.alloc((size_t)2 * nall), "alloc ext_apow");
+  CK(c->f01.alloc((size_t)4 * n), "alloc f01");
+  CK(c->f01v.alloc((size_t)4 * n), "alloc f01v");
+  CK(c->fv.alloc((size_t)2 * n), "alloc fv");
+  c->fri_coef.resize(c->n_steps + 1);
+  c->fri_vals.resize(c->n_steps + 1);
+  c->fri_trees.resize(c->n_steps);
+  size_t gather_words = 0;
+  {
+    uint32_t ds = d;
+    const size_t cap_per = ((size_t)1 << c->cap_h) >> c->rate_bits;
+    for (uint32_t s = 0; s <= c->n_steps; s++) {
+      CK(c->fri_coef[s].alloc((size_t)2 << ds), "alloc fri coef");
+      if (s < c->n_steps) {
+        CK(c->fri_vals[s].alloc((size_t)2 * C << ds), "alloc fri vals");
+        uint32_t ab = c->arity[s];
+        if (ab < 1 || ab > 4 || ds < ab || (((size_t)1 << ds) >> ab) < cap_per) {
+          return fail(P2GPU_E_BLOB, "unsupported FRI reduction arity");
+        }
+        if (tree_alloc(c->fri_trees[s], C, ((size_t)1 << ds) >> ab, cap_per)) {
+          std::string keep = g_err;
+          circuit_release(c);
+          delete c;
+          g_err = keep;
+          return P2GPU_E_DEVICE;
+        }
+        gather_words += (2u << ab) + 4 * (size_t)(ds + c->rate_bits);
+        ds -= ab;
+      }
+    }
+  }
+  gather_words += nall + 4 * 4 * (size_t)(d + c->rate_bits);
+  c->gather_cap = gather_words * c->num_queries + 64;
+  CK(c->gather_ptrs.alloc(c->gather_cap), "alloc gather");
+  CK(c->gather_out.alloc(c->gather_cap), "alloc gather");
+  CK(c->pow_result.alloc(1), "alloc pow");
+
+  // ---- constants_sigmas commitment (the prover-side part of `build()`) ----
+  {
+    // stage values [constants | sigmas] in the wires buffer region of the cs LDE (reuse cs.lde as scratch)
+    gl_t *stage = c->cs.lde.p;
+    CK(hipMemcpyAsync(stage, constants, 8 * (size_t)c->NC * n, hipMemcpyHostToDevice, st), "copy constants");
+    CK(hipMemcpyAsync(stage + (size_t)c->NC * n, c->d_sigmas.p, 8 * (size_t)c->R * n, hipMemcpyDeviceToDevice, st), "copy sigmas");
+    {
+      gl_t ninv = gl_inv((gl_t)n);
+      ntt_batch(st, 0, stage, c->cs.coeffs.p, d, ncs, 1, c->tw_inv.p, 0, nullptr, ninv, false);
+    }
+    if (int rc = batch_commit_from_coeffs(c, c->cs)) {
+      std::string keep = g_err;
+      circuit_release(c);
+      delete c;
+      g_err = keep;
+      return rc;
+    }
+  }
+  if (cap_in) {
+    for (size_t i = 0; i < c->cs.cap.size(); i++)
+      if (memcmp(cap_in + 32 * i, c->cs.cap[i].w, 25)) return fail(P2GPU_E_CAP_MISMATCH, "constants_sigmas cap mismatch");
+  }
+  if (c->flags & 1) {
+    memset(&c->circuit_digest, 0, sizeof(dig_t));
+    memcpy(c->circuit_digest.w, &h[32], 25);
+  } else {
+    // circuit_builder.rs build(): H::hash_no_pad(cap.flatten() || hash_pad([]).to_vec() || [degree_bits])  [P2-recall]
+    std::vector<gl_t> parts;
+    for (auto &dg : c->cs.cap) {
+      gl_t e[4];
+      dig_to_elems(dg, e);
+      parts.insert(parts.end(), e, e + 4);
+    }
+    std::vector<gl_t> pad(12, 0);
+    pad[0] = 1;
+    pad[11] = 1;
+    dig_t ds = host_hash_no_pad(pad);
+    gl_t e[4];
+    dig_to_elems(ds, e);
+    parts.insert(parts.end(), e, e + 4);
+    parts.push_back(d);
+    c->circuit_digest = host_hash_no_pad(parts);
+  }
+  CK(hipStreamSynchronize(st), "sync");
+#undef CK
+  *out_c = c;
+  return P2GPU_OK;
+}
+
+void p2gpu_circuit_destroy(p2gpu_circuit *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  circuit_release(c);
+  delete c;
+}
+
+int p2gpu_circuit_cap(const p2gpu_circuit *c, uint8_t *out) {
+  if (!c || !out) return P2GPU_E_ARG;
+  for (size_t i = 0; i < c->cs.cap.size(); i++) memcpy(out + 25 * i, c->cs.cap[i].w, 25);
+  return P2GPU_OK;
+}
+int p2gpu_circuit_digest(const p2gpu_circuit *c, uint8_t out[25]) {
+  if (!c || !out) return P2GPU_E_ARG;
+  memcpy(out, c->circuit_digest.w, 25);
+  return P2GPU_OK;
+}
+
+int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) {
+  if (!c || !key) return P2GPU_E_ARG;
+  std::string k(key);
+  if (k == "pow_hint") c->pow_hint = value;
+  else if (k == "profile") {
+    c->profile = (int)value;
+    c->kstats.clear();
+  } else {
+    set_err("unknown knob %s", key);
+    return P2GPU_E_ARG;
+  }
+  return P2GPU_OK;
+}
+
+// per-kernel event timings accumulated while "profile" = 1: writes up to `cap`
+// entries "name\0" (64 B each) + total ms + launch count; returns the number of entries
+int p2gpu_kernel_stats(p2gpu_circuit *c, char *names, double *ms, double *bytes, uint64_t *launches, int cap) {
+  if (!c) return P2GPU_E_ARG;
+  int i = 0;
+  for (auto &kv : c->kstats) {
+    if (i >= cap) break;
+    snprintf(names + 64 * i, 64, "%s", kv.first.c_str());
+    ms[i] = kv.second.ms;
+    bytes[i] = kv.second.bytes;
+    launches[i] = kv.second.launches;
+    i++;
+  }
+  return i;
+}
+
+int p2gpu_prove_dev(p2gpu_circuit *c, const uint64_t *wires_dev, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
+                    size_t *proof_len, p2gpu_timings *tm) {
+  if (!c || !wires_dev || !proof_out || !proof_len) return P2GPU_E_ARG;
+  return prove_impl(c, wires_dev, pis, n_pi, proof_out, proof_len, tm, 0.0);
+}
+
+int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
+                size_t *proof_len, p2gpu_timings *tm) {
+  if (!c || !wires || !proof_out || !proof_len) return P2GPU_E_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  double t0 = now_ms();
+  HIP_TRY(hipMemcpyAsync(c->wires_vals.p, wires, 8 * (size_t)c->W * c->n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  double h2d = now_ms() - t0;
+  return prove_impl(c, c->wires_vals.p, pis, n_pi, proof_out, proof_len, tm, h2d);
+}
+
+// ---- stage-level operators (host buffers) ----
+int p2gpu_ifft_batch(const uint64_t *vals, size_t ncols, unsigned d, uint64_t *coeffs_out) {
+  if (int rc = ensure_device()) return rc;
+  if (!vals || !coeffs_out || d > 24) return P2GPU_E_ARG;
+  Scratch S;
+  HIP_TRY(hipStreamCreate(&S.st));
+  size_t n = (size_t)1 << d, half = n >= 2 ? n / 2 : 1;
+  gl_t *a = S.alloc<gl_t>(ncols * n), *b = S.alloc<gl_t>(ncols * n), *tw = S.alloc<gl_t>(half);
+  if (!a || !b || !tw) { set_err("hipMalloc failed"); return P2GPU_E_DEVICE; }
+  HIP_TRY(hipMemcpyAsync(a, vals, 8 * ncols * n, hipMemcpyHostToDevice, S.st));
+  fill_powers(S.st, tw, gl_inv(gl_root(d)), (uint32_t)half);
+  ntt_batch(S.st, 0, a, b, d, (uint32_t)ncols, 1, tw, 0, nullptr, gl_inv((gl_t)n), false);
+  bitrev_cols(S.st, b, a, d, (uint32_t)ncols);  // natural-order coefficients for the caller
+  HIP_TRY(hipMemcpyAsync(coeffs_out, a, 8 * ncols * n, hipMemcpyDeviceToHost, S.st));
+  HIP_TRY(hipStreamSynchronize(S.st));
+  return P2GPU_OK;
+}
+
+int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned rate_bits, uint64_t *lde_out) {
+  if (int rc = ensure_device()) return rc;
+  if (!coeffs || !lde_out || d > 24 || rate_bits > 3) return P2GPU_E_ARG;
+  Scratch S;
+  HIP_TRY(hipStreamCreate(&S.st));
+  size_t n = (size_t)1 << d, half = n >= 2 ? n / 2 : 1;
+  uint32_t C = 1u << rate_bits;
+  gl_t *a = S.alloc<gl_t>(ncols * n), *b = S.alloc<gl_t>(ncols * n), *tw = S.alloc<gl_t>(half);
+  gl_t *scale = S.alloc<gl_t>(C * n), *lde = S.alloc<gl_t>(C * ncols * n);
+  if (!a || !b || !tw || !scale || !lde) { set_err("hipMalloc failed"); return P2GPU_E_DEVICE; }
+  HIP_TRY(hipMemcpyAsync(a, coeffs, 8 * ncols * n, hipMemcpyHostToDevice, S.st));
+  bitrev_cols(S.st, a, b, d, (uint32_t)ncols);
+  fill_powers(S.st, tw, gl_root(d), (uint32_t)half);
+  fill_coset_scale(S.st, scale, GL_GEN, gl_root(d + rate_bits), d, C, 1);
+  ntt_batch(S.st, 1, b, lde, d, (uint32_t)ncols, C, tw, 0, scale, 1, false);
+  // [C][cols][n] -> natural order per column: out[col][C*k + r]
+  std::vector<gl_t> tmp(C * ncols * n);
+  HIP_TRY(hipMemcpyAsync(tmp.data(), lde, 8 * tmp.size(), hipMemcpyDeviceToHost, S.st));
+  HIP_TRY(hipStreamSynchronize(S.st));
+  for (uint32_t r = 0; r < C; r++)
+    for (size_t col = 0; col < ncols; col++)
+      for (size_t k = 0; k < n; k++) lde_out[col * C * n + C * k + r] = tmp[((size_t)r * ncols + col) * n + k];
+  return P2GPU_OK;
+}
+
+int p2gpu_hash_rows(const uint64_t *rows, size_t n_rows, size_t row_len, uint8_t *digests_out) {
+  if (int rc = ensure_device()) return rc;
+  if (!rows || !digests_out) return P2GPU_E_ARG;
+  Scratch S;
+  HIP_TRY(hipStreamCreate(&S.st));
+  gl_t *a = S.alloc<gl_t>(n_rows * row_len);
+  dig_t *dg = S.alloc<dig_t>(n_rows);
+  if (!a || !dg) { set_err("hipMalloc failed"); return P2GPU_E_DEVICE; }
+  HIP_TRY(hipMemcpyAsync(a, rows, 8 * n_rows * row_len, hipMemcpyHostToDevice, S.st));
+  hash_rows(S.st, a, n_rows, (uint32_t)row_len, dg);
+  std::vector<dig_t> h(n_rows);
+  HIP_TRY(hipMemcpyAsync(h.data(), dg, sizeof(dig_t) * n_rows, hipMemcpyDeviceToHost, S.st));
+  HIP_TRY(hipStreamSynchronize(S.st));
+  for (size_t i = 0; i < n_rows; i++) memcpy(digests_out + 25 * i, h[i].w, 25);
+  return P2GPU_OK;
+}
+
+int p2gpu_commit_values(const uint64_t *vals, size_t ncols, unsigned d, unsigned rate_bits, unsigned cap_h,
+                        uint8_t *cap_out) {
+  if (int rc = ensure_device()) return rc;
+  if (!vals || !cap_out || d > 24 || rate_bits > 3 || cap_h < rate_bits || cap_h > rate_bits + d) return P2GPU_E_ARG;
+  // a throw-away circuit-like context with just the tables and one batch
+  p2gpu_circuit *c = new p2gpu_circuit();
+  c->d = d; c->rate_bits = rate_bits; c->cap_h = cap_h; c->n = (size_t)1 << d; c->N = c->n << rate_bits;
+  c->C = 1u << rate_bits; c->device = g_device; c->n_steps = 0;
+  int rc = P2GPU_OK;
+  size_t n = c->n, half = n >= 2 ? n / 2 : 1;
+  do {
+    if (hipStreamCreate(&c->stream) != hipSuccess || c->tw_fwd.alloc(half) != hipSuccess ||
+        c->tw_inv.alloc(half) != hipSuccess || c->scale.alloc((size_t)c->C * n) != hipSuccess ||
+        c->wires_vals.alloc(ncols * n) != hipSuccess) {
+      set_err("hipMalloc failed");
+      rc = P2GPU_E_DEVICE;
+      break;
+    }
+    if ((rc = batch_alloc(c, c->wires, (uint32_t)ncols))) break;
+    fill_powers(c->stream, c->tw_fwd.p, gl_root(d), (uint32_t)half);
+    fill_powers(c->stream, c->tw_inv.p, gl_inv(gl_root(d)), (uint32_t)half);
+    fill_coset_scale(c->stream, c->scale.p, GL_GEN, gl_root(d + rate_bits), d, c->C, 1);
+    if (hipMemcpyAsync(c->wires_vals.p, vals, 8 * ncols * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+      set_err("copy failed");
+      rc = P2GPU_E_DEVICE;
+      break;
+    }
+    if ((rc = batch_commit_from_values(c, c->wires, c->wires_vals.p))) break;
+    for (size_t i = 0; i < c->wires.cap.size(); i++) memcpy(cap_out + 25 * i, c->wires.cap[i].w, 25);
+  } while (0);
+  circuit_release(c);
+  delete c;
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,244 @@
+"""ctypes binding of libp2gpu.so (include/p2gpu.h) with the reference's names.
+
+Mirrors, for the hot path only:
+  * ``CircuitData<F, C, D>``            -> :class:`CircuitData` (built from the circuit blob the
+    Rust side exports once per circuit; see include/p2gpu.h)
+  * ``circuit_data.prove(witnesses)``   -> :meth:`CircuitData.prove`
+    (plonky2-backend/src/actions/prove_action.rs:96; test twin
+    circuit_translation/tests/factories/utils.rs:26)
+  * ``ProofWithPublicInputs::to_bytes`` -> :meth:`ProofWithPublicInputs.to_bytes`
+    (prove_action.rs:75-78; compression stays on the Rust side)
+Errors surface as :class:`P2GpuError` carrying the library's message, where the
+reference would `unwrap()` an `anyhow::Error`.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+UINT64_MAX = (1 << 64) - 1
+
+
+class P2GpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"p2gpu error {code}: {msg}")
+        self.code = code
+
+
+class _Timings(ctypes.Structure):
+    _fields_ = [
+        ("wires_commit_ms", ctypes.c_double),
+        ("zs_commit_ms", ctypes.c_double),
+        ("quotient_ms", ctypes.c_double),
+        ("openings_ms", ctypes.c_double),
+        ("fri_ms", ctypes.c_double),
+        ("total_ms", ctypes.c_double),
+        ("h2d_ms", ctypes.c_double),
+        ("pow_witness", ctypes.c_uint64),
+    ]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libp2gpu.so")
+
+
+def load_library():
+    """Load libp2gpu.so.  Fails loudly when the HIP extension is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise P2GpuError(-8, f"{path} is missing: build it with __graft_entry__.build() (hipcc, gfx950)")
+    lib = ctypes.CDLL(path)
+    vp, sz, u8p = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p
+    lib.p2gpu_last_error.restype = ctypes.c_char_p
+    lib.p2gpu_init.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    lib.p2gpu_circuit_create.argtypes = [u8p, sz, ctypes.POINTER(vp)]
+    lib.p2gpu_circuit_destroy.argtypes = [vp]
+    lib.p2gpu_circuit_destroy.restype = None
+    lib.p2gpu_circuit_cap.argtypes = [vp, u8p]
+    lib.p2gpu_circuit_digest.argtypes = [vp, u8p]
+    lib.p2gpu_proof_size_bound.argtypes = [vp]
+    lib.p2gpu_proof_size_bound.restype = sz
+    lib.p2gpu_prove.argtypes = [vp, vp, vp, ctypes.c_uint32, u8p, ctypes.POINTER(sz), ctypes.POINTER(_Timings)]
+    lib.p2gpu_prove_dev.argtypes = lib.p2gpu_prove.argtypes
+    lib.p2gpu_circuit_set.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64]
+    lib.p2gpu_kernel_stats.argtypes = [vp, ctypes.c_char_p, vp, vp, vp, ctypes.c_int]
+    lib.p2gpu_ifft_batch.argtypes = [vp, sz, ctypes.c_uint, vp]
+    lib.p2gpu_lde_batch.argtypes = [vp, sz, ctypes.c_uint, ctypes.c_uint, vp]
+    lib.p2gpu_commit_values.argtypes = [vp, sz, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, u8p]
+    lib.p2gpu_hash_rows.argtypes = [vp, sz, sz, u8p]
+    lib.p2gpu_device_info.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(sz)]
+    _LIB = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise P2GpuError(rc, load_library().p2gpu_last_error().decode(errors="replace"))
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a
+
+
+def device_info():
+    lib = load_library()
+    name = ctypes.create_string_buffer(256)
+    cu = ctypes.c_int()
+    mem = ctypes.c_size_t()
+    _check(lib.p2gpu_device_info(name, 256, ctypes.byref(cu), ctypes.byref(mem)))
+    return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+
+class ProofWithPublicInputs:
+    """Uncompressed proof bytes in plonky2's ``ProofWithPublicInputs::to_bytes`` layout."""
+
+    def __init__(self, data, timings=None):
+        self._data = bytes(data)
+        self.timings = timings or {}
+
+    def to_bytes(self):
+        return self._data
+
+    def __len__(self):
+        return len(self._data)
+
+    def __eq__(self, other):
+        return isinstance(other, ProofWithPublicInputs) and self._data == other._data
+
+
+class CircuitData:
+    """Prover-side circuit handle (device-resident constants/sigmas oracle, root tables)."""
+
+    def __init__(self, blob):
+        lib = load_library()
+        self._lib = lib
+        self._blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
+        hdr = self._blob[:256].view(np.uint32)
+        self.degree_bits = int(hdr[2])
+        self.num_wires = int(hdr[3])
+        self.rate_bits = int(hdr[9])
+        self.cap_height = int(hdr[10])
+        self.num_public_inputs = int(hdr[24])
+        self._h = ctypes.c_void_p()
+        _check(lib.p2gpu_circuit_create(self._blob.ctypes.data, self._blob.nbytes, ctypes.byref(self._h)))
+        self._bound = lib.p2gpu_proof_size_bound(self._h)
+
+    @classmethod
+    def from_blob(cls, blob):
+        return cls(blob)
+
+    @property
+    def degree(self):
+        return 1 << self.degree_bits
+
+    def constants_sigmas_cap(self):
+        out = np.zeros(25 << self.cap_height, dtype=np.uint8)
+        _check(self._lib.p2gpu_circuit_cap(self._h, out.ctypes.data))
+        return out.tobytes()
+
+    def circuit_digest(self):
+        out = np.zeros(25, dtype=np.uint8)
+        _check(self._lib.p2gpu_circuit_digest(self._h, out.ctypes.data))
+        return out.tobytes()
+
+    def set(self, key, value):
+        _check(self._lib.p2gpu_circuit_set(self._h, key.encode(), ctypes.c_uint64(value)))
+
+    def kernel_stats(self):
+        cap = 64
+        names = ctypes.create_string_buffer(64 * cap)
+        ms = np.zeros(cap, dtype=np.float64)
+        by = np.zeros(cap, dtype=np.float64)
+        ln = np.zeros(cap, dtype=np.uint64)
+        k = self._lib.p2gpu_kernel_stats(self._h, names, ms.ctypes.data, by.ctypes.data, ln.ctypes.data, cap)
+        out = {}
+        for i in range(max(k, 0)):
+            nm = names.raw[64 * i:64 * (i + 1)].split(b"\0", 1)[0].decode()
+            out[nm] = {"ms": float(ms[i]), "bytes": float(by[i]), "launches": int(ln[i])}
+        return out
+
+    def prove(self, wires, public_inputs=()):
+        """``circuit_data.prove(witnesses)``: `wires` is the full witness matrix
+        [num_wires][degree] (numpy uint64 on the host, or a torch tensor on the
+        circuit's GPU, which is read in place)."""
+        pis = _u64(np.array(list(public_inputs), dtype=np.uint64))
+        out = np.zeros(self._bound, dtype=np.uint8)
+        plen = ctypes.c_size_t(out.nbytes)
+        tm = _Timings()
+        expect = self.num_wires * self.degree
+        if hasattr(wires, "data_ptr") and getattr(wires, "is_cuda", False):
+            if wires.numel() != expect or wires.element_size() != 8 or not wires.is_contiguous():
+                raise P2GpuError(-7, "wires tensor must be contiguous int64/uint64 [num_wires][degree]")
+            rc = self._lib.p2gpu_prove_dev(self._h, ctypes.c_void_p(wires.data_ptr()), pis.ctypes.data, len(pis),
+                                           out.ctypes.data, ctypes.byref(plen), ctypes.byref(tm))
+        else:
+            w = _u64(wires)
+            if w.size != expect:
+                raise P2GpuError(-7, f"wires must be [num_wires={self.num_wires}][degree={self.degree}]")
+            rc = self._lib.p2gpu_prove(self._h, w.ctypes.data, pis.ctypes.data, len(pis), out.ctypes.data,
+                                       ctypes.byref(plen), ctypes.byref(tm))
+        _check(rc)
+        t = {f: getattr(tm, f) for f, _ in _Timings._fields_}
+        return ProofWithPublicInputs(out[:plen.value].tobytes(), t)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.p2gpu_circuit_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- stage-level operators ---------------------------------------------------
+def ifft_batch(vals):
+    """PolynomialValues::ifft on every row of `vals` [ncols][2^d]."""
+    lib = load_library()
+    v = _u64(vals)
+    ncols, n = v.shape
+    d = n.bit_length() - 1
+    out = np.zeros_like(v)
+    _check(lib.p2gpu_ifft_batch(v.ctypes.data, ncols, d, out.ctypes.data))
+    return out
+
+
+def lde_batch(coeffs, rate_bits=3):
+    """PolynomialCoeffs::lde(rate_bits).coset_fft(7) on every row of `coeffs`."""
+    lib = load_library()
+    c = _u64(coeffs)
+    ncols, n = c.shape
+    d = n.bit_length() - 1
+    out = np.zeros((ncols, n << rate_bits), dtype=np.uint64)
+    _check(lib.p2gpu_lde_batch(c.ctypes.data, ncols, d, rate_bits, out.ctypes.data))
+    return out
+
+
+def commit_values(vals, rate_bits=3, cap_height=4):
+    """PolynomialBatch::from_values(...).merkle_tree.cap as bytes (2^cap_height x 25)."""
+    lib = load_library()
+    v = _u64(vals)
+    ncols, n = v.shape
+    d = n.bit_length() - 1
+    out = np.zeros(25 << cap_height, dtype=np.uint8)
+    _check(lib.p2gpu_commit_values(v.ctypes.data, ncols, d, rate_bits, cap_height, out.ctypes.data))
+    return out.tobytes()
+
+
+def hash_rows(rows):
+    """KeccakHash<25>::hash_or_noop of every row."""
+    lib = load_library()
+    r = _u64(rows)
+    n_rows, row_len = r.shape
+    out = np.zeros(25 * n_rows, dtype=np.uint8)
+    _check(lib.p2gpu_hash_rows(r.ctypes.data, n_rows, row_len, out.ctypes.data))
+    return out.reshape(n_rows, 25)

@@ -1,0 +1,48 @@
+"""Synthetic circuits with the reference's shape (workload generator, host only).
+
+See csrc/synth.cpp: wide_ecc_config (plonky2-backend/src/circuit_translation/mod.rs:69)
+with gate-mix presets `arith`, `sha`, `ecdsa`; satisfying wire values from a seed.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def synth_lib_path():
+    return os.path.join(_HERE, "libp2synth.so")
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = synth_lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run __graft_entry__.build()")
+        _LIB = ctypes.CDLL(path)
+        _LIB.p2synth_free.argtypes = [ctypes.c_void_p]
+        _LIB.p2synth_free.restype = None
+    return _LIB
+
+
+def make_circuit(degree_bits, mix="arith", seed=1):
+    """Returns (blob: np.uint8[...], wires: np.uint64[num_wires][2^degree_bits])."""
+    lib = _lib()
+    blob = ctypes.POINTER(ctypes.c_uint8)()
+    blen = ctypes.c_size_t()
+    wires = ctypes.POINTER(ctypes.c_uint64)()
+    nw = ctypes.c_uint32()
+    rc = lib.p2synth_make(ctypes.c_uint(degree_bits), mix.encode(), ctypes.c_uint64(seed), ctypes.byref(blob),
+                          ctypes.byref(blen), ctypes.byref(wires), ctypes.byref(nw))
+    if rc != 0:
+        raise ValueError(f"p2synth_make({degree_bits}, {mix!r}) failed: {rc}")
+    try:
+        b = np.ctypeslib.as_array(blob, (blen.value,)).copy()
+        w = np.ctypeslib.as_array(wires, (nw.value, 1 << degree_bits)).copy()
+    finally:
+        lib.p2synth_free(blob)
+        lib.p2synth_free(wires)
+    return b, w

@@ -111,8 +111,13 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *public_
  * circuit's device; it is only read. */
 int p2gpu_prove_dev(p2gpu_circuit *c, const uint64_t *wires_dev, const uint64_t *public_inputs, uint32_t n_pi,
                     uint8_t *proof_out, size_t *proof_len, p2gpu_timings *opt_timings);
-/* optional knobs: "pow_hint" (u64), "self_check" (0/1) */
+/* optional knobs: "pow_hint" (u64; UINT64_MAX = grind), "profile" (0/1: time every
+ * kernel launch with HIP events on the launch stream; resets the statistics) */
 int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value);
+/* statistics accumulated while "profile" = 1, one entry per kernel symbol:
+ * names[64*i] (NUL-terminated), total milliseconds, total algorithmic bytes,
+ * launch count.  Returns the number of entries written (<= cap). */
+int p2gpu_kernel_stats(p2gpu_circuit *c, char *names, double *ms, double *bytes, uint64_t *launches, int cap);
 
 /* stage-level operators (host buffers in/out; used by the parity tests) */
 /* values [ncols][2^d] -> coefficients [ncols][2^d], natural order */

@@ -23,3 +23,4 @@ from .prover import (  # noqa: F401
     load_library,
 )
 from .synth import make_circuit, synth_lib_path  # noqa: F401
+from . import parallel  # noqa: F401,E402

@@ -202,8 +202,20 @@ int circuit_load(circuit_t *c, const uint8_t *blob, size_t len) {
   }
   return 0;
 }
+int circuit_load_verifier(circuit_t *c, const uint8_t *blob, size_t len, const uint8_t *cap, const uint8_t *digest) {
+  int rc = circuit_parse(c, blob, len);
+  if (rc) return rc;
+  size_t ncap = (size_t)1 << c->cap_height;
+  c->vcap = (digest_t *)malloc(sizeof(digest_t) * ncap);
+  for (size_t i = 0; i < ncap; i++) memcpy(c->vcap[i].b, cap + DIGEST_BYTES * i, DIGEST_BYTES);
+  c->cs.tree.cap = c->vcap;
+  memcpy(c->circuit_digest.b, digest, DIGEST_BYTES);
+  return 0;
+}
 void circuit_free(circuit_t *c) {
   free(c->gates);
   c->gates = NULL;
+  free(c->vcap);
+  c->vcap = NULL;
   if (c->cs.coeffs) batch_free(&c->cs);
 }

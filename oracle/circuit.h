@@ -66,12 +66,16 @@ typedef struct {
   /* derived by circuit_load (plonky2 `build`): oracle 0 and the digest */
   batch_t cs;
   digest_t circuit_digest;
+  digest_t *vcap; /* verifier-only mode: cap supplied by the caller */
 } circuit_t;
 
 /* returns 0 ok; <0 error.  Keeps pointers into blob (caller keeps it alive). */
 int circuit_parse(circuit_t *c, const uint8_t *blob, size_t len);
 /* parse + constants_sigmas commitment + circuit digest */
 int circuit_load(circuit_t *c, const uint8_t *blob, size_t len);
+/* verifier-only: parse + take the constants_sigmas cap (2^cap_height x 25 B) and digest as given
+ * (VerifierOnlyCircuitData), no commitment is computed */
+int circuit_load_verifier(circuit_t *c, const uint8_t *blob, size_t len, const uint8_t *cap, const uint8_t *digest);
 void circuit_free(circuit_t *c);
 
 uint32_t gate_num_constraints(uint32_t kind, const uint32_t p[4]);

@@ -101,7 +101,7 @@ digest_t kh_hash_pad(const gl_t *elems, size_t n) {
   while ((m + 1) % 12 != 0) m++;
   m++;
   gl_t *p = (gl_t *)calloc(m, sizeof(gl_t));
-  memcpy(p, elems, n * sizeof(gl_t));
+  if (n) memcpy(p, elems, n * sizeof(gl_t));
   p[n] = 1;
   p[m - 1] = 1;
   digest_t d = kh_hash_no_pad(p, m);

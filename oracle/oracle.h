@@ -48,6 +48,9 @@ typedef struct {
 #define ORC_E_ZETA_IN_SUBGROUP -4
 
 int orc_circuit_create(const uint8_t *blob, size_t len, orc_circuit **out);
+/* verifier-only handle (VerifierCircuitData): cap = 2^cap_height x 25 B, no commitment work */
+int orc_circuit_create_verifier(const uint8_t *blob, size_t len, const uint8_t *cap, const uint8_t digest[25],
+                                orc_circuit **out);
 void orc_circuit_destroy(orc_circuit *c);
 /* copies 2^cap_height digests of 25 bytes each */
 void orc_circuit_cap(const orc_circuit *c, uint8_t *out);

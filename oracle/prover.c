@@ -54,6 +54,22 @@ int orc_circuit_create(const uint8_t *blob, size_t len, orc_circuit **out) {
   *out = oc;
   return ORC_OK;
 }
+int orc_circuit_create_verifier(const uint8_t *blob, size_t len, const uint8_t *cap, const uint8_t digest[25],
+                                orc_circuit **out) {
+  orc_circuit *oc = (orc_circuit *)calloc(1, sizeof *oc);
+  /* only the header, gate table and k_is are needed: keep a private copy of the whole blob */
+  oc->blob = (uint8_t *)malloc(len);
+  memcpy(oc->blob, blob, len);
+  int rc = circuit_load_verifier(&oc->c, oc->blob, len, cap, digest);
+  if (rc) {
+    circuit_free(&oc->c);
+    free(oc->blob);
+    free(oc);
+    return ORC_E_BLOB;
+  }
+  *out = oc;
+  return ORC_OK;
+}
 void orc_circuit_destroy(orc_circuit *oc) {
   if (!oc) return;
   circuit_free(&oc->c);

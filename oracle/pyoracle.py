@@ -47,6 +47,7 @@ def lib():
         L = ctypes.CDLL(path)
         vp, sz = ctypes.c_void_p, ctypes.c_size_t
         L.orc_circuit_create.argtypes = [vp, sz, ctypes.POINTER(vp)]
+        L.orc_circuit_create_verifier.argtypes = [vp, sz, vp, vp, ctypes.POINTER(vp)]
         L.orc_circuit_destroy.argtypes = [vp]
         L.orc_circuit_destroy.restype = None
         L.orc_circuit_cap.argtypes = [vp, vp]
@@ -91,10 +92,18 @@ def _u64(a):
 
 
 class OracleCircuit:
-    def __init__(self, blob):
+    def __init__(self, blob, verifier_cap=None, verifier_digest=None):
+        """Full (prover + verifier) handle, or verifier-only when the constants_sigmas cap and the
+        circuit digest are supplied (plonky2 VerifierCircuitData: no commitment is recomputed)."""
         self._blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self._h = ctypes.c_void_p()
-        rc = lib().orc_circuit_create(self._blob.ctypes.data, self._blob.nbytes, ctypes.byref(self._h))
+        if verifier_cap is not None:
+            cap = np.frombuffer(verifier_cap, dtype=np.uint8)
+            dg = np.frombuffer(verifier_digest, dtype=np.uint8)
+            rc = lib().orc_circuit_create_verifier(self._blob.ctypes.data, self._blob.nbytes, cap.ctypes.data,
+                                                   dg.ctypes.data, ctypes.byref(self._h))
+        else:
+            rc = lib().orc_circuit_create(self._blob.ctypes.data, self._blob.nbytes, ctypes.byref(self._h))
         if rc != 0:
             raise ValueError(f"orc_circuit_create failed: {rc}")
         hdr = self._blob[:256].view(np.uint32)

@@ -1,0 +1,117 @@
+"""The oracle's prover/verifier pair on small circuits (CPU only).
+
+Mirrors the reference's system-level invariant -- every in-tree test ends in
+`assert!(circuit_data.verify(proof).is_ok())` (e.g. tests/test_precompiled.rs:43) -- plus
+negatives in the style of its `should_panic` range-check tests (test_blackbox.rs:17,36,55):
+an unsatisfied witness or a tampered proof must be rejected.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, P
+
+
+@pytest.mark.parametrize("d,mix,seed", [(5, "arith", 1), (6, "sha", 2), (8, "ecdsa", 3), (10, "ecdsa", 4)])
+def test_prove_then_verify(pkg, orc, d, mix, seed):
+    blob, wires = pkg.make_circuit(d, mix, seed)
+    oc = orc.OracleCircuit(blob)
+    proof, tr = oc.prove(wires)
+    assert oc.verify(proof)
+    # deterministic: same inputs, same bytes (minimum PoW witness policy)
+    proof2, _ = oc.prove(wires)
+    assert proof == proof2
+    # a verifier-only handle (cap + digest as in VerifierCircuitData) accepts the same proof
+    ov = orc.OracleCircuit(blob, verifier_cap=oc.cap(), verifier_digest=oc.digest())
+    assert ov.verify(proof)
+    # the PoW response really has >= 16 leading zero bits and the witness is minimal
+    assert tr.pow_witness < (1 << 40)
+    p_hint, _ = oc.prove(wires, pow_hint=int(tr.pow_witness))
+    assert p_hint == proof
+
+
+def test_golden_proof_digests(pkg, orc):
+    with open(os.path.join(GOLDEN, "proof_digests.json")) as f:
+        gold = json.load(f)
+    for g in gold:
+        blob, wires = pkg.make_circuit(g["degree_bits"], g["mix"], g["seed"])
+        assert hashlib.sha256(blob.tobytes()).hexdigest() == g["blob_sha256"]
+        assert hashlib.sha256(wires.tobytes()).hexdigest() == g["wires_sha256"]
+        oc = orc.OracleCircuit(blob)
+        assert hashlib.sha256(oc.cap()).hexdigest() == g["constants_sigmas_cap_sha256"]
+        assert oc.digest().hex() == g["circuit_digest"]
+        proof, tr = oc.prove(wires)
+        assert len(proof) == g["proof_len"]
+        assert hashlib.sha256(proof).hexdigest() == g["proof_sha256"]
+        assert [int(x) for x in tr.betas[:2]] == g["betas"] and [int(x) for x in tr.zeta] == g["zeta"]
+        assert int(tr.pow_witness) == g["pow_witness"]
+
+
+def test_unsatisfied_witness_is_rejected(pkg, orc):
+    blob, wires = pkg.make_circuit(7, "ecdsa", 9)
+    oc = orc.OracleCircuit(blob)
+    for (col, row) in ((3, 5), (0, 2), (100, 40)):
+        bad = wires.copy()
+        bad[col, row] = (int(bad[col, row]) + 1) % P
+        proof, _ = oc.prove(bad)
+        assert not oc.verify(proof)
+
+
+def test_tampered_proof_is_rejected(pkg, orc):
+    blob, wires = pkg.make_circuit(6, "sha", 4)
+    oc = orc.OracleCircuit(blob)
+    proof, _ = oc.prove(wires)
+    assert oc.verify(proof)
+    n = len(proof)
+    # caps, openings, commit-phase caps, a query leaf, final poly, pow witness
+    for pos in (0, 3 * 16 * 25 + 8, 3 * 16 * 25 + 16 * 400, n // 2, n - 16, n - 8):
+        bad = bytearray(proof)
+        bad[pos] ^= 1
+        assert not oc.verify(bytes(bad)), pos
+    assert not oc.verify(proof[:-1]) and not oc.verify(proof + b"\0")
+
+
+def test_proof_layout_sizes(pkg, orc):
+    """C.11: 3 caps | openings | step caps | 28 x (4 initial leaves+paths, step leaves+paths) | final | pow."""
+    d = 9
+    blob, wires = pkg.make_circuit(d, "arith", 1)
+    hdr = blob[:256].view(np.uint32)
+    nc, R, W, K, QF = int(hdr[5]), int(hdr[4]), int(hdr[3]), int(hdr[7]), int(hdr[8])
+    steps = [int(x) for x in hdr[14:14 + int(hdr[13])]]
+    assert steps == [4]  # ConstantArityBits(4, 5): d=9 -> one reduction, final poly 2^5
+    nzp, nq = K * 10, K * QF
+    size = 3 * 16 * 25 + 16 * (nc + R + W + nzp + nq + K) + len(steps) * 16 * 25
+    per_q = sum(8 * c + 1 + 25 * (d + 3 - 4) for c in (nc + R, W, nzp, nq))
+    lg = d + 3
+    for ab in steps:
+        lg -= ab
+        per_q += 16 * (1 << ab) + 1 + 25 * (lg - 4)
+    size += 28 * per_q + 16 * (1 << (d - sum(steps))) + 8
+    proof, _ = orc.OracleCircuit(blob).prove(wires)
+    assert len(proof) == size
+
+
+def test_blob_rejects_garbage(pkg, orc):
+    blob, _ = pkg.make_circuit(5, "arith", 1)
+    bad = blob.copy()
+    bad[0] ^= 0xFF
+    with pytest.raises(ValueError):
+        orc.OracleCircuit(bad)
+    with pytest.raises(ValueError):
+        orc.OracleCircuit(blob[:1000])
+
+
+def test_synth_selector_groups(pkg):
+    """selectors.rs: 4 gates (max degree 3) fit one selector; the 12-gate ecdsa mix needs 3 groups."""
+    b1, _ = pkg.make_circuit(5, "arith", 1)
+    b2, _ = pkg.make_circuit(5, "ecdsa", 1)
+    h1, h2 = b1[:256].view(np.uint32), b2[:256].view(np.uint32)
+    assert (int(h1[23]), int(h1[6]), int(h1[5])) == (4, 1, 3)
+    assert (int(h2[23]), int(h2[6]), int(h2[5])) == (12, 3, 5)
+    gates = b2[256:256 + 48 * 12].view(np.uint32).reshape(12, 12)
+    degs = [int(g[9]) for g in gates]
+    assert degs == sorted(degs)
+    assert [tuple(int(x) for x in g[6:8]) for g in gates] == [(0, 5)] * 5 + [(5, 10)] * 5 + [(10, 12)] * 2

@@ -82,9 +82,8 @@ struct QuotArgs {
   uint32_t tw_shift, d, rate_bits, W, R, NC, num_selectors, K, QF, nchunks, PP, num_gates, nterms;
   gl_t betas[MAX_CHALLENGES], gammas[MAX_CHALLENGES];
   gl_t pi_hash[4];
-  gl_t coset_shift[8];  // 7 * w_N^r
-  gl_t zh_inv[8];       // 1 / (7^n w_8^r - 1)
-  gl_t zh[8];
+  const gl_t *qconst;   // device [3][8]: coset shift 7 w_N^r | Z_H = 7^n w_8^r - 1 | 1 / Z_H
+                        // (in memory, not kernel arguments: they are indexed by blockIdx.y)
   gl_t n_inv;           // 1/n
 };
 void quotient_eval(hipStream_t st, const QuotArgs &a);

@@ -176,6 +176,17 @@ __device__ __forceinline__ gl_t range4(gl_t v) {
   return gl_mul(a, b);
 }
 
+template <int LVL, class WF>
+__device__ __forceinline__ gl_t ra_fold(WF &W, uint32_t item0, const gl_t *bv) {
+  if constexpr (LVL == 0) {
+    return W(item0);
+  } else {
+    gl_t x = ra_fold<LVL - 1>(W, item0, bv);
+    gl_t y = ra_fold<LVL - 1>(W, item0 + (1u << (LVL - 1)), bv);
+    return gl_add(x, gl_mul(bv[LVL - 1], gl_sub(y, x)));
+  }
+}
+
 // W(c): wire column c of this row; LC(i): local constant i
 template <class WF, class CF>
 __device__ __forceinline__ void eval_gate(const GateDesc &g, WF W, CF LC, const gl_t *pih, Consumer &out) {
@@ -217,19 +228,24 @@ __device__ __forceinline__ void eval_gate(const GateDesc &g, WF W, CF LC, const 
       gl_t rec = 0;
       for (uint32_t b = bits; b-- > 0;) rec = gl_add(gl_dbl(rec), W(bw + b));
       out.emit(gl_sub(rec, W(base)));
-      // fold the list: items[i] selected by the bits, lowest bit first
-      gl_t items[64];
-      for (uint32_t i = 0; i < vec; i++) items[i] = W(base + 2 + i);
-      uint32_t len = vec;
-      for (uint32_t b = 0; b < bits; b++) {
-        gl_t bv = W(bw + b);
-        for (uint32_t i = 0; i < len / 2; i++) {
-          gl_t x = items[2 * i], y = items[2 * i + 1];
-          items[i] = gl_add(x, gl_mul(bv, gl_sub(y, x)));
-        }
-        len >>= 1;
+      // fold the list: the nested multiplexer x + b (y - x), lowest bit innermost (same
+      // expression tree as folding pairs level by level), evaluated depth-first with
+      // compile-time indices so nothing spills to scratch
+      gl_t bv[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (uint32_t b = 0; b < 6; b++)
+        if (b < bits) bv[b] = W(bw + b);
+      gl_t folded;
+      switch (bits) {
+      case 1: folded = ra_fold<1>(W, base + 2, bv); break;
+      case 2: folded = ra_fold<2>(W, base + 2, bv); break;
+      case 3: folded = ra_fold<3>(W, base + 2, bv); break;
+      case 4: folded = ra_fold<4>(W, base + 2, bv); break;
+      case 5: folded = ra_fold<5>(W, base + 2, bv); break;
+      case 6: folded = ra_fold<6>(W, base + 2, bv); break;
+      default: folded = W(base + 2); break;
       }
-      out.emit(gl_sub(items[0], W(base + 1)));
+      out.emit(gl_sub(folded, W(base + 1)));
     }
     for (uint32_t i = 0; i < extra; i++) out.emit(gl_sub(LC(i), W((2 + vec) * copies + i)));
     break;
@@ -355,7 +371,7 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotArgs a) {
   const gl_t *wl = a.wires_lde + (size_t)r * a.W * n + k;
   const gl_t *zl = a.zp_lde + (size_t)r * nzp * n;  // indexed with explicit k (next row)
   const uint32_t kn = (k + 1) & (n - 1);
-  const gl_t x = gl_mul(a.coset_shift[r], root_pow(a.tw, a.tw_shift, a.d, k));
+  const gl_t x = gl_mul(a.qconst[r], root_pow(a.tw, a.tw_shift, a.d, k));
   Consumer out;
   out.acc0 = 0;
   out.acc1 = 0;
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotArgs a) {
   out.ap1 = a.apow + a.nterms;
   out.t = 0;
   // L_0(x) (Z_c(x) - 1),  L_0(x) = Z_H(x) / (n (x - 1))
-  const gl_t l0 = gl_mul(gl_mul(a.zh[r], a.n_inv), gl_inv(gl_sub(x, 1)));
+  const gl_t l0 = gl_mul(gl_mul(a.qconst[8 + r], a.n_inv), gl_inv(gl_sub(x, 1)));
   for (uint32_t c = 0; c < a.K; c++) out.emit(gl_mul(l0, gl_sub(zl[(size_t)c * n + k], 1)));
   // partial-product checks: prev * prod(num) - next * prod(den), chunk by chunk, both challenges
   {
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotArgs a) {
     tot0 = gl_add(tot0, gl_mul(f, out.acc0));
     tot1 = gl_add(tot1, gl_mul(f, out.acc1));
   }
-  const gl_t zi = a.zh_inv[r];
+  const gl_t zi = a.qconst[16 + r];
   a.out[((size_t)0 * (1u << a.rate_bits) + r) * n + k] = gl_mul(tot0, zi);
   if (a.K > 1) a.out[((size_t)1 * (1u << a.rate_bits) + r) * n + k] = gl_mul(tot1, zi);
 }

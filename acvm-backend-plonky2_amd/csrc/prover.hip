@@ -47,6 +47,24 @@ void set_err(const char *fmt, ...) {
     }                                                                                          \
   } while (0)
 
+// P2GPU_TRACE=1: synchronise after every phase and report progress on stderr (debugging aid)
+bool trace_on() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("P2GPU_TRACE");
+    v = (e && *e && *e != '0') ? 1 : 0;
+  }
+  return v == 1;
+}
+#define TRACE(c, label)                                                                     \
+  do {                                                                                      \
+    if (trace_on()) {                                                                       \
+      hipError_t e_ = hipStreamSynchronize((c)->stream);                                    \
+      fprintf(stderr, "[p2gpu] %s: %s\n", label, e_ == hipSuccess ? "ok" : hipGetErrorString(e_)); \
+      fflush(stderr);                                                                       \
+    }                                                                                       \
+  } while (0)
+
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -154,7 +172,7 @@ struct p2gpu_circuit {
   int device = 0;
   hipStream_t stream = nullptr;
   // tables
-  DBuf<gl_t> tw_fwd, tw_inv, scale, inv_scale, d_kis, d_sigmas, fri_scale;
+  DBuf<gl_t> tw_fwd, tw_inv, scale, inv_scale, d_kis, d_sigmas, fri_scale, qconst;
   DBuf<GateDesc> d_gates;
   // oracles
   Batch cs, wires, zp, quot;
@@ -264,6 +282,7 @@ int batch_commit_from_coeffs(p2gpu_circuit *c, Batch &b) {
   {
     hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, c->C, b.dig.p);
   }
+  TRACE(c, "  lde + leaf hash");
   return tree_build(c, b, c->n);
 }
 int batch_commit_from_values(p2gpu_circuit *c, Batch &b, const gl_t *vals_dev) {
@@ -271,6 +290,7 @@ int batch_commit_from_values(p2gpu_circuit *c, Batch &b, const gl_t *vals_dev) {
     gl_t ninv = gl_inv((gl_t)c->n);
     ntt_batch(c->stream, 0, vals_dev, b.coeffs.p, c->d, b.cols, 1, c->tw_inv.p, 0, nullptr, ninv, false);
   }
+  TRACE(c, "  inverse ntt");
   return batch_commit_from_coeffs(c, b);
 }
 int batch_alloc(p2gpu_circuit *c, Batch &b, uint32_t cols) {
@@ -337,7 +357,9 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   gl_t pih[4] = {0, 0, 0, 0};  // InnerHasher(Poseidon).hash_no_pad([]) = 0^4
 
   // ---- 1. wires commitment ----
+  TRACE(c, "enter");
   if (int rc = batch_commit_from_values(c, c->wires, wires_dev)) return rc;
+  TRACE(c, "wires commit");
   Challenger ch;
   ch.observe_digest(c->circuit_digest);
   for (int i = 0; i < 4; i++) ch.observe(pih[i]);
@@ -363,6 +385,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     a.zp = c->zp_vals.p;
     zs_partial_products(st, a, c->scan_tmp.p);
   }
+  TRACE(c, "zs_partial_products");
   if (int rc = batch_commit_from_values(c, c->zp, c->zp_vals.p)) return rc;
   ch.observe_cap(c->zp.cap);
   for (uint32_t k = 0; k < K; k++) alphas[k] = ch.get();
@@ -397,15 +420,13 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     for (uint32_t k = 0; k < 2; k++) { q.betas[k] = betas[k]; q.gammas[k] = gammas[k]; }
     for (int i = 0; i < 4; i++) q.pi_hash[i] = pih[i];
     gl_t wN = gl_root(d + c->rate_bits), wC = gl_root(c->rate_bits), gn = gl_pow(GL_GEN, n);
-    for (uint32_t r = 0; r < C; r++) {
-      q.coset_shift[r] = gl_mul(GL_GEN, gl_pow(wN, r));
-      q.zh[r] = gl_sub(gl_mul(gn, gl_pow(wC, r)), 1);
-      q.zh_inv[r] = gl_inv(q.zh[r]);
-    }
+    q.qconst = c->qconst.p;
+    (void)wN;
     q.n_inv = gl_inv((gl_t)n);
     {
       quotient_eval(st, q);
     }
+    TRACE(c, "quotient_eval");
     // coset_ifft of size N = per-coset inverse transforms + cross-coset butterflies
     {
       ntt_batch(st, 0, c->qvals.p, c->qtmp.p, d, K * C, 1, c->tw_inv.p, 0, nullptr, q.n_inv, false);
@@ -414,6 +435,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
       quotient_chunks(st, c->qtmp.p, c->inv_scale.p, c->quot.coeffs.p, d, K, c->rate_bits, gl_inv(wC), gl_inv(gn),
                       gl_inv((gl_t)C));
     }
+    TRACE(c, "quotient_chunks");
   }
   if (int rc = batch_commit_from_coeffs(c, c->quot)) return rc;
   ch.observe_cap(c->quot.cap);
@@ -458,6 +480,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
       op[j] = ext_make(a0, a1);
     }
   }
+  TRACE(c, "openings");
   for (size_t j = 0; j < nall + K; j++) ch.observe_ext(op[j]);
   t0 = now_ms();
   T.openings_ms = t0 - t1;
@@ -493,10 +516,11 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     {
       ntt_batch(st, 0, c->fv.p, c->fri_coef[0].p, d, 2, 1, c->tw_inv.p, 0, nullptr, gl_inv((gl_t)n), false);
     }
-    {
+    if (c->n_steps > 0) {  // no reduction step (degree <= 2^5): the values are never committed
       ntt_batch(st, 1, c->fri_coef[0].p, c->fri_vals[0].p, d, 2, C, c->tw_fwd.p, 0, c->scale.p, 1, false);
     }
   }
+  TRACE(c, "fri final poly lde");
   std::vector<ext_t> fri_betas;
   uint32_t ds = d;
   gl_t shift = GL_GEN;
@@ -531,6 +555,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     }
   }
   for (auto &e : final_poly) ch.observe_ext(e);
+  TRACE(c, "fri commit phase");
 
   // PoW: minimum-witness policy (upstream's parallel find_any is not deterministic)
   uint64_t pow_witness = c->pow_hint;
@@ -565,6 +590,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     return P2GPU_E_ARG;
   }
   T.pow_witness = pow_witness;
+  TRACE(c, "pow");
   std::vector<size_t> qidx(c->num_queries);
   for (auto &x : qidx) x = (size_t)(ch.get() % N);
 
@@ -678,7 +704,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
 
 void circuit_release(p2gpu_circuit *c) {
   c->tw_fwd.release(); c->tw_inv.release(); c->scale.release(); c->inv_scale.release(); c->d_kis.release();
-  c->d_sigmas.release(); c->fri_scale.release(); c->d_gates.release();
+  c->d_sigmas.release(); c->fri_scale.release(); c->d_gates.release(); c->qconst.release(); c->qconst.release();
   c->cs.release(); c->wires.release(); c->zp.release(); c->quot.release();
   c->wires_vals.release(); c->zp_vals.release(); c->cp.release(); c->rowprod.release(); c->scan_tmp.release();
   c->apow.release(); c->qvals.release(); c->qtmp.release(); c->pw.release(); c->partial.release();
@@ -884,6 +910,32 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   fill_powers(st, c->tw_inv.p, gl_inv(wn), (uint32_t)half);
   fill_coset_scale(st, c->scale.p, GL_GEN, wN, d, C, 1);
   fill_coset_scale(st, c->inv_scale.p, gl_inv(GL_GEN), gl_inv(wN), d, C, 1);
+  CK(c->qconst.alloc(24), "alloc qconst");
+  {
+    // ZeroPolyOnCoset: Z_H on the LDE coset has period 2^rate_bits
+    gl_t qc[24];
+    memset(qc, 0, sizeof qc);
+    gl_t wC = gl_root(c->rate_bits), gn = gl_pow(GL_GEN, n);
+    for (uint32_t r = 0; r < C; r++) {
+      qc[r] = gl_mul(GL_GEN, gl_pow(wN, r));
+      qc[8 + r] = gl_sub(gl_mul(gn, gl_pow(wC, r)), 1);
+      qc[16 + r] = gl_inv(qc[8 + r]);
+    }
+    CK(hipMemcpy(c->qconst.p, qc, sizeof qc, hipMemcpyHostToDevice), "copy qconst");
+  }
+  CK(c->qconst.alloc(24), "alloc qconst");
+  {
+    // ZeroPolyOnCoset: Z_H on the LDE coset has period 2^rate_bits
+    gl_t qc[24];
+    memset(qc, 0, sizeof qc);
+    gl_t wC = gl_root(c->rate_bits), gn = gl_pow(GL_GEN, n);
+    for (uint32_t r = 0; r < C; r++) {
+      qc[r] = gl_mul(GL_GEN, gl_pow(wN, r));
+      qc[8 + r] = gl_sub(gl_mul(gn, gl_pow(wC, r)), 1);
+      qc[16 + r] = gl_inv(qc[8 + r]);
+    }
+    CK(hipMemcpy(c->qconst.p, qc, sizeof qc, hipMemcpyHostToDevice), "copy qconst");
+  }
   CK(hipMemcpyAsync(c->d_kis.p, k_is, 8 * (size_t)c->R, hipMemcpyHostToDevice, st), "copy kis");
   CK(hipMemcpyAsync(c->d_sigmas.p, sigmas, 8 * (size_t)c->R * n, hipMemcpyHostToDevice, st), "copy sigmas");
   if (c->num_gates)

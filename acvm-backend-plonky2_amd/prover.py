@@ -53,6 +53,14 @@ def load_library():
     path = lib_path()
     if not os.path.exists(path):
         raise P2GpuError(-8, f"{path} is missing: build it with __graft_entry__.build() (hipcc, gfx950)")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
+    # /opt/rocm's).  Importing torch FIRST makes libp2gpu.so bind to that already-loaded runtime,
+    # so torch tensors (device memory, streams) and our kernels share one context; loading in
+    # the other order maps two runtimes and the second one sees no devices.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is part of the target image
+        pass
     lib = ctypes.CDLL(path)
     vp, sz, u8p = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p
     lib.p2gpu_last_error.restype = ctypes.c_char_p

@@ -1,6 +1,7 @@
 // internal.hpp -- declarations shared by the HIP translation units of libp2gpu.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include "gl.hpp"
 #include "keccak.hpp"
 
@@ -34,12 +35,24 @@ struct ProfScope {
 };
 
 // ---- ntt.hip ----
-// dit = 0: DIF, natural in -> bit-reversed out; dit = 1: DIT, bit-reversed in -> natural out.
+struct NttPass {
+  uint32_t s, a, tb, nrounds;
+  uint32_t r[4], tw_off[4];
+};
+struct NttPlan {
+  uint32_t d = 0;
+  int dit = 0;           // 0: DIF natural in -> bit-reversed out; 1: DIT bit-reversed in -> natural out
+  bool inverse = false;  // roots w^-1 (the 1/n factor is the caller's `post`)
+  std::vector<NttPass> passes;
+  gl_t *ptw = nullptr;   // device: packed per-round twiddle tables
+  size_t table_len = 0;
+};
+NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse);
+void ntt_plan_destroy(NttPlan *p);
 // src [cols][n] (or [cosets][cols][n] when src_per_coset), dst [cosets][cols][n].
-// tw: powers of the (forward or inverse) primitive root of a size n << tw_shift.
 // scale (DIT only): [cosets][n] multiplied into the input; post: multiplied into the output.
-void ntt_batch(hipStream_t st, int dit, const gl_t *src, gl_t *dst, uint32_t d, uint32_t cols, uint32_t cosets,
-               const gl_t *tw, uint32_t tw_shift, const gl_t *scale, gl_t post, bool src_per_coset);
+void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
+               const gl_t *scale, gl_t post, bool src_per_coset);
 void fill_powers(hipStream_t st, gl_t *out, gl_t root, uint32_t count);
 void fill_coset_scale(hipStream_t st, gl_t *out, gl_t shift, gl_t wN, uint32_t d, uint32_t cosets, gl_t mult);
 void bitrev_cols(hipStream_t st, const gl_t *in, gl_t *out, uint32_t d, uint32_t cols);
@@ -54,6 +67,8 @@ void hash_fri_leaves(hipStream_t st, const gl_t *vals, uint32_t lg_npc, uint32_t
                      dig_t *dig);
 // one tree level: in [cosets][m] -> out [cosets][m/2], out[c][k] = H(in[c][k], in[c][k + m/2])
 void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m);
+// every level below one with m <= 4096 nodes per coset, down to cap_per nodes per coset, in one launch
+void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per);
 
 // ---- plonk.hip ----
 struct ZsArgs {

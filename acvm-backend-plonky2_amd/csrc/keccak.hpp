@@ -21,37 +21,81 @@ struct alignas(32) dig_t {
 
 P2_HD uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 forms: three-input bit ops (v_bitop3_b32: xor3 = 0x96, chi a^(~b&c) = 0xD2) and
+// v_alignbit_b32 rotates on the 32-bit halves -- 180 VALU per round instead of ~290.
+__device__ __forceinline__ uint64_t kx3(uint64_t a, uint64_t b, uint64_t c) {
+  uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0x96);
+  uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0x96);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t kchi(uint64_t a, uint64_t b, uint64_t c) {
+  uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0xD2);
+  uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0xD2);
+  return ((uint64_t)hi << 32) | lo;
+}
+template <int N>
+__device__ __forceinline__ uint64_t krot(uint64_t x) {
+  const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  if constexpr (N == 0) {
+    return x;
+  } else if constexpr (N == 32) {
+    return ((uint64_t)lo << 32) | hi;
+  } else if constexpr (N < 32) {
+    uint32_t nh = __builtin_amdgcn_alignbit(hi, lo, 32 - N), nl = __builtin_amdgcn_alignbit(lo, hi, 32 - N);
+    return ((uint64_t)nh << 32) | nl;
+  } else {
+    uint32_t nh = __builtin_amdgcn_alignbit(lo, hi, 64 - N), nl = __builtin_amdgcn_alignbit(hi, lo, 64 - N);
+    return ((uint64_t)nh << 32) | nl;
+  }
+}
+#define P2_KX3(a, b, c) kx3(a, b, c)
+#define P2_KCHI(a, b, c) kchi(a, b, c)
+#define P2_KROT(x, n) krot<n>(x)
+#else
+#define P2_KX3(a, b, c) ((a) ^ (b) ^ (c))
+#define P2_KCHI(a, b, c) ((a) ^ (~(b) & (c)))
+#define P2_KROT(x, n) rotl64(x, n)
+#endif
+
 #define P2_KECCAK_ROUND(RC)                                                                                            \
   {                                                                                                                    \
-    uint64_t c0 = a00 ^ a05 ^ a10 ^ a15 ^ a20, c1 = a01 ^ a06 ^ a11 ^ a16 ^ a21, c2 = a02 ^ a07 ^ a12 ^ a17 ^ a22,       \
-             c3 = a03 ^ a08 ^ a13 ^ a18 ^ a23, c4 = a04 ^ a09 ^ a14 ^ a19 ^ a24;                                        \
-    uint64_t d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1), d3 = c2 ^ rotl64(c4, 1),       \
-             d4 = c3 ^ rotl64(c0, 1);                                                                                  \
-    a00 ^= d0; a05 ^= d0; a10 ^= d0; a15 ^= d0; a20 ^= d0;                                                             \
-    a01 ^= d1; a06 ^= d1; a11 ^= d1; a16 ^= d1; a21 ^= d1;                                                             \
-    a02 ^= d2; a07 ^= d2; a12 ^= d2; a17 ^= d2; a22 ^= d2;                                                             \
-    a03 ^= d3; a08 ^= d3; a13 ^= d3; a18 ^= d3; a23 ^= d3;                                                             \
-    a04 ^= d4; a09 ^= d4; a14 ^= d4; a19 ^= d4; a24 ^= d4;                                                             \
+    uint64_t c0 = P2_KX3(P2_KX3(a00, a05, a10), a15, a20), c1 = P2_KX3(P2_KX3(a01, a06, a11), a16, a21),               \
+             c2 = P2_KX3(P2_KX3(a02, a07, a12), a17, a22), c3 = P2_KX3(P2_KX3(a03, a08, a13), a18, a23),               \
+             c4 = P2_KX3(P2_KX3(a04, a09, a14), a19, a24);                                                             \
+    uint64_t r0 = P2_KROT(c0, 1), r1 = P2_KROT(c1, 1), r2 = P2_KROT(c2, 1), r3 = P2_KROT(c3, 1), r4 = P2_KROT(c4, 1);  \
+    /* theta: a[x][y] ^= c[x-1] ^ rot(c[x+1], 1) */                                                                    \
+    a00 = P2_KX3(a00, c4, r1); a05 = P2_KX3(a05, c4, r1); a10 = P2_KX3(a10, c4, r1); a15 = P2_KX3(a15, c4, r1);        \
+    a20 = P2_KX3(a20, c4, r1);                                                                                         \
+    a01 = P2_KX3(a01, c0, r2); a06 = P2_KX3(a06, c0, r2); a11 = P2_KX3(a11, c0, r2); a16 = P2_KX3(a16, c0, r2);        \
+    a21 = P2_KX3(a21, c0, r2);                                                                                         \
+    a02 = P2_KX3(a02, c1, r3); a07 = P2_KX3(a07, c1, r3); a12 = P2_KX3(a12, c1, r3); a17 = P2_KX3(a17, c1, r3);        \
+    a22 = P2_KX3(a22, c1, r3);                                                                                         \
+    a03 = P2_KX3(a03, c2, r4); a08 = P2_KX3(a08, c2, r4); a13 = P2_KX3(a13, c2, r4); a18 = P2_KX3(a18, c2, r4);        \
+    a23 = P2_KX3(a23, c2, r4);                                                                                         \
+    a04 = P2_KX3(a04, c3, r0); a09 = P2_KX3(a09, c3, r0); a14 = P2_KX3(a14, c3, r0); a19 = P2_KX3(a19, c3, r0);        \
+    a24 = P2_KX3(a24, c3, r0);                                                                                         \
     /* rho + pi: B[y][2x+3y] = rot(A[x][y]) */                                                                         \
-    uint64_t b00 = a00, b10 = rotl64(a01, 1), b20 = rotl64(a02, 62), b05 = rotl64(a03, 28), b15 = rotl64(a04, 27);     \
-    uint64_t b16 = rotl64(a05, 36), b01 = rotl64(a06, 44), b11 = rotl64(a07, 6), b21 = rotl64(a08, 55),                \
-             b06 = rotl64(a09, 20);                                                                                    \
-    uint64_t b07 = rotl64(a10, 3), b17 = rotl64(a11, 10), b02 = rotl64(a12, 43), b12 = rotl64(a13, 25),                \
-             b22 = rotl64(a14, 39);                                                                                    \
-    uint64_t b23 = rotl64(a15, 41), b08 = rotl64(a16, 45), b18 = rotl64(a17, 15), b03 = rotl64(a18, 21),               \
-             b13 = rotl64(a19, 8);                                                                                     \
-    uint64_t b14 = rotl64(a20, 18), b24 = rotl64(a21, 2), b09 = rotl64(a22, 61), b19 = rotl64(a23, 56),                \
-             b04 = rotl64(a24, 14);                                                                                    \
-    a00 = b00 ^ (~b01 & b02); a01 = b01 ^ (~b02 & b03); a02 = b02 ^ (~b03 & b04); a03 = b03 ^ (~b04 & b00);            \
-    a04 = b04 ^ (~b00 & b01);                                                                                          \
-    a05 = b05 ^ (~b06 & b07); a06 = b06 ^ (~b07 & b08); a07 = b07 ^ (~b08 & b09); a08 = b08 ^ (~b09 & b05);            \
-    a09 = b09 ^ (~b05 & b06);                                                                                          \
-    a10 = b10 ^ (~b11 & b12); a11 = b11 ^ (~b12 & b13); a12 = b12 ^ (~b13 & b14); a13 = b13 ^ (~b14 & b10);            \
-    a14 = b14 ^ (~b10 & b11);                                                                                          \
-    a15 = b15 ^ (~b16 & b17); a16 = b16 ^ (~b17 & b18); a17 = b17 ^ (~b18 & b19); a18 = b18 ^ (~b19 & b15);            \
-    a19 = b19 ^ (~b15 & b16);                                                                                          \
-    a20 = b20 ^ (~b21 & b22); a21 = b21 ^ (~b22 & b23); a22 = b22 ^ (~b23 & b24); a23 = b23 ^ (~b24 & b20);            \
-    a24 = b24 ^ (~b20 & b21);                                                                                          \
+    uint64_t b00 = a00, b10 = P2_KROT(a01, 1), b20 = P2_KROT(a02, 62), b05 = P2_KROT(a03, 28), b15 = P2_KROT(a04, 27); \
+    uint64_t b16 = P2_KROT(a05, 36), b01 = P2_KROT(a06, 44), b11 = P2_KROT(a07, 6), b21 = P2_KROT(a08, 55),            \
+             b06 = P2_KROT(a09, 20);                                                                                   \
+    uint64_t b07 = P2_KROT(a10, 3), b17 = P2_KROT(a11, 10), b02 = P2_KROT(a12, 43), b12 = P2_KROT(a13, 25),            \
+             b22 = P2_KROT(a14, 39);                                                                                   \
+    uint64_t b23 = P2_KROT(a15, 41), b08 = P2_KROT(a16, 45), b18 = P2_KROT(a17, 15), b03 = P2_KROT(a18, 21),           \
+             b13 = P2_KROT(a19, 8);                                                                                    \
+    uint64_t b14 = P2_KROT(a20, 18), b24 = P2_KROT(a21, 2), b09 = P2_KROT(a22, 61), b19 = P2_KROT(a23, 56),            \
+             b04 = P2_KROT(a24, 14);                                                                                   \
+    /* chi */                                                                                                          \
+    a00 = P2_KCHI(b00, b01, b02); a01 = P2_KCHI(b01, b02, b03); a02 = P2_KCHI(b02, b03, b04);                          \
+    a03 = P2_KCHI(b03, b04, b00); a04 = P2_KCHI(b04, b00, b01);                                                        \
+    a05 = P2_KCHI(b05, b06, b07); a06 = P2_KCHI(b06, b07, b08); a07 = P2_KCHI(b07, b08, b09);                          \
+    a08 = P2_KCHI(b08, b09, b05); a09 = P2_KCHI(b09, b05, b06);                                                        \
+    a10 = P2_KCHI(b10, b11, b12); a11 = P2_KCHI(b11, b12, b13); a12 = P2_KCHI(b12, b13, b14);                          \
+    a13 = P2_KCHI(b13, b14, b10); a14 = P2_KCHI(b14, b10, b11);                                                        \
+    a15 = P2_KCHI(b15, b16, b17); a16 = P2_KCHI(b16, b17, b18); a17 = P2_KCHI(b17, b18, b19);                          \
+    a18 = P2_KCHI(b18, b19, b15); a19 = P2_KCHI(b19, b15, b16);                                                        \
+    a20 = P2_KCHI(b20, b21, b22); a21 = P2_KCHI(b21, b22, b23); a22 = P2_KCHI(b22, b23, b24);                          \
+    a23 = P2_KCHI(b23, b24, b20); a24 = P2_KCHI(b24, b20, b21);                                                        \
     a00 ^= (RC);                                                                                                       \
   }
 

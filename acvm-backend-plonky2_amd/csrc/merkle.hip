@@ -97,6 +97,32 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(const dig_t *__restri
   out[(size_t)c * half + k] = keccak_two_to_one(l, r);
 }
 
+// All remaining levels of a tree in ONE launch once a level has <= 4096 nodes per coset: one
+// 1024-thread block per coset walks the levels (each level is one Keccak-f of dependent
+// latency; separate launches would add a boundary per level).  Levels are laid out back to
+// back: level with m nodes per coset at `lvl`, the next one at lvl + cosets * m.
+__global__ __launch_bounds__(1024) void merkle_tail_kernel(dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per) {
+  const uint32_t c = blockIdx.x;
+  while (m > cap_per) {
+    const uint32_t half = m >> 1;
+    const dig_t *in = lvl + (size_t)c * m;
+    dig_t *out = lvl + (size_t)cosets * m + (size_t)c * half;
+    for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
+      const dig_t l = in[k], r = in[k + half];
+      out[k] = keccak_two_to_one(l, r);
+    }
+    __syncthreads();
+    lvl += (size_t)cosets * m;
+    m = half;
+  }
+}
+void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per) {
+  if (m <= cap_per) return;
+  ProfScope ps("merkle_tail_kernel", 96.0 * cosets * (double)(m - cap_per));
+  uint32_t threads = m / 2 >= 1024 ? 1024 : (m / 2 >= 64 ? m / 2 : 64);
+  hipLaunchKernelGGL(merkle_tail_kernel, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per);
+}
+
 void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig) {
   size_t n = (size_t)1 << d;
   uint32_t threads = n >= 256 ? 256 : 64;

@@ -1,4 +1,5 @@
-// ntt.hip -- batched radix-2 Goldilocks NTT for gfx950, LDS-tiled.
+// ntt.hip -- batched Goldilocks NTT for gfx950: LDS-tiled passes, radix-16/8/4/2
+// register rounds with shift twiddles.
 //
 // Replaces (inside `circuit_data.prove`, plonky2-backend/src/actions/prove_action.rs:96)
 // plonky2 0.2.2 field/src/fft.rs `fft_classic` / `ifft` and
@@ -11,81 +12,154 @@
 //     (bit-reversed in, natural out) with coset shifts 7*w_N^r, r < 8; natural
 //     LDE row i = 8k + r is output k of coset r.  No transpose, no bit-reversal
 //     pass and no zero-padded 8n-point FFT ever touches HBM.
-// A transform of 2^d points is split into passes of <= 12 layers; each pass
-// stages a 2^12-element tile (32 KB + padding) in LDS, keeps 16 elements per
-// lane in registers for 4 butterfly layers at a time, and reads/writes HBM in
-// runs of >= 128 contiguous bytes.  HBM-bound target; 64-bit modular products
-// come from 32-bit multiplies (no MFMA: integer prime-field work).
+// A transform of 2^d points is split into passes of <= 12 layers; a pass stages a
+// 2^12-element tile (32 KB + padding) in LDS and reads/writes HBM in runs of
+// >= 128 contiguous bytes.  Inside a pass the layers are done in rounds of up to
+// four: a lane holds 16 elements in registers, multiplies them by 15 per-group
+// twiddles (one coalesced load each from a table packed per round -- no index
+// arithmetic, no scattered root-table gathers) and then runs a 16-point DFT whose
+// internal twiddles are powers of w_16 = 2^156 = -2^60, i.e. shifts (2 is a 192nd
+// root of unity in Goldilocks): 15 general modmuls per 16 elements per four
+// layers instead of 32.  This kernel is integer-ALU bound on gfx950 (a 64x64
+// modmul is ~29 VALU); the HBM traffic equals the algorithmic bytes.  No MFMA.
 #include "internal.hpp"
+#include <map>
+#include <mutex>
+#include <type_traits>
+#include <vector>
 
 namespace p2 {
 
-// LDS index padding: one extra slot per 16 so that 16-element strides do not
-// collide on LDS banks
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// x * 2^E mod p for a compile-time 0 <= E < 96 (canonical in, canonical out)
+template <int E>
+__device__ __forceinline__ gl_t mul_pow2(gl_t x) {
+  if constexpr (E == 0) {
+    return x;
+  } else if constexpr (E < 32) {
+    const uint64_t lo = x << E;
+    const uint32_t hi = (uint32_t)(x >> (64 - E));  // < 2^E
+    const uint64_t t1 = ((uint64_t)hi << 32) - hi;  // hi * (2^32 - 1)
+    uint64_t t2 = lo + t1;
+    if (t2 < t1) t2 += GL_EPS;
+    return gl_canon(t2);
+  } else if constexpr (E < 64) {
+    return gl_reduce128(x << E, x >> (64 - E));
+  } else {
+    return mul_pow2<32>(mul_pow2<E - 32>(x));
+  }
+}
+
+// exponent of 2 for the constant twiddle w_{2^(lam+1)}^q (w_64 = 2^39), mod 192
+__host__ __device__ constexpr int tw_exp(int lam, int q, bool inv) {
+  int e = (39 * (32 >> lam) * q) % 192;
+  return inv ? (192 - e) % 192 : e;
+}
+__host__ __device__ constexpr int brev_c(int x, int bits) {
+  int r = 0;
+  for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+  return r;
+}
+
+// in-register 2^LOGR-point DFT; DIT: bit-reversed in -> natural out; DIF: natural in -> bit-reversed out
+template <int LOGR, int DIT, bool INV>
+__device__ __forceinline__ void dft_regs(gl_t (&v)[1 << LOGR]) {
+  constexpr int R = 1 << LOGR;
+  static_for<0, LOGR>([&](auto lc) {
+    constexpr int lam = DIT ? decltype(lc)::value : LOGR - 1 - decltype(lc)::value;
+    static_for<0, R>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr ((j & (1 << lam)) == 0) {
+        constexpr int k = j | (1 << lam);
+        constexpr int e = tw_exp(lam, j & ((1 << lam) - 1), INV);
+        if constexpr (DIT) {
+          const gl_t u = v[j];
+          if constexpr (e < 96) {
+            const gl_t t = mul_pow2<e>(v[k]);
+            v[j] = gl_add(u, t);
+            v[k] = gl_sub(u, t);
+          } else {
+            const gl_t t = mul_pow2<e - 96>(v[k]);  // twiddle = -2^(e-96)
+            v[j] = gl_sub(u, t);
+            v[k] = gl_add(u, t);
+          }
+        } else {
+          const gl_t u = v[j], x = v[k];
+          v[j] = gl_add(u, x);
+          if constexpr (e < 96) v[k] = mul_pow2<e>(gl_sub(u, x));
+          else v[k] = mul_pow2<e - 96>(gl_sub(x, u));
+        }
+      }
+    });
+  });
+}
+
+// LDS index padding: one extra slot per 16 so that 16-element strides do not collide on banks
 __device__ __forceinline__ uint32_t pidx(uint32_t e) { return e + (e >> 4); }
 
+constexpr int MAX_ROUNDS = 4;
 struct PassArgs {
-  const gl_t *src;   // [cols][n] (coset passes read the same src for every coset)
-  gl_t *dst;         // [cosets][cols][n]
-  const gl_t *tw;    // root powers w_m^i, i < m/2, for some m >= n (stride tw_stride)
-  const gl_t *scale; // optional per-position scale [cosets][n] applied on load (DIT first pass)
-  gl_t post;         // scale applied on store (1/n for the inverse), 1 = none
-  uint32_t d;        // log2 n
-  uint32_t s;        // log2 global stride of the tile's lowest butterfly layer
-  uint32_t a;        // number of layers in this pass
-  uint32_t tb;       // log2 contiguous run (tile = 2^(a+tb) elements)
-  uint32_t tw_shift; // log2(m / n)
+  const gl_t *src;    // [cols][n] (or [cosets][cols][n])
+  gl_t *dst;          // [cosets][cols][n]
+  const gl_t *ptw;    // packed per-round twiddles of this plan
+  const gl_t *scale;  // optional [cosets][n], multiplied into the input of the first DIT pass
+  gl_t post;          // multiplied into the output of the last pass (1 = none)
+  uint32_t d;         // log2 n
+  uint32_t s;         // log2 global stride of the pass's lowest layer
+  uint32_t a;         // layers in this pass
+  uint32_t tb;        // log2 contiguous run; tile = 2^(a+tb)
   uint32_t cols;
-  uint32_t src_coset_stride_zero;  // 1: src is not indexed by coset
+  uint32_t src_single;  // 1: src has no coset dimension
+  uint32_t nrounds;
+  uint32_t r[MAX_ROUNDS];       // layers per round, ascending tile bit
+  uint32_t tw_off[MAX_ROUNDS];  // offset of the round's table in ptw
 };
 
-// global index of tile element e
 __device__ __forceinline__ uint32_t gidx(uint32_t e, uint32_t hi_base, uint32_t lo0, uint32_t s, uint32_t tb) {
   return hi_base + ((e >> tb) << s) + lo0 + (e & ((1u << tb) - 1));
 }
 
-template <int DIT, int LOGR>
-__device__ __forceinline__ void round_regs(gl_t *lds, const PassArgs &A, uint32_t TB, uint32_t beta0, uint32_t lo0) {
+// one round: layers on tile bits [beta0, beta0 + LOGR); the group twiddle of position j is
+// theta^(bitrev(j)), theta = w_{2^(s0+LOGR)}^(lo), read from the packed table T[(e-1)*M + lo]
+template <int DIT, bool INV, int LOGR>
+__device__ __forceinline__ void round_regs(gl_t *lds, const PassArgs &A, uint32_t TB, uint32_t beta0, uint32_t lo0,
+                                           const gl_t *tw) {
   constexpr int R = 1 << LOGR;
   const uint32_t ngroups = 1u << (TB - LOGR);
+  const uint32_t s0 = beta0 - A.tb + A.s;  // log2 M
+  const uint32_t M = 1u << s0;
   for (uint32_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
-    uint32_t low = g & ((1u << beta0) - 1), high = g >> beta0;
-    uint32_t base = (high << (beta0 + LOGR)) | low;
+    const uint32_t low = g & ((1u << beta0) - 1), high = g >> beta0;
+    const uint32_t base = (high << (beta0 + LOGR)) | low;
+    // global index of `base` modulo M
+    const uint32_t lo = (((base & ((1u << beta0) - 1)) >> A.tb) << A.s) + lo0 + (base & ((1u << A.tb) - 1));
     gl_t v[R];
 #pragma unroll
     for (int j = 0; j < R; j++) v[j] = lds[pidx(base | ((uint32_t)j << beta0))];
-    // position of `base` in the global index space, modulo the layer stride
     if (DIT) {
-#pragma unroll
-      for (int lam = 0; lam < LOGR; lam++) {
-        uint32_t beta = beta0 + lam;
-        uint32_t lgS = beta - A.tb + A.s;  // log2 global stride of this layer
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-          if (j & (1 << lam)) continue;
-          uint32_t e = base | ((uint32_t)j << beta0);
-          uint32_t gm = (((e & ((1u << beta) - 1)) >> A.tb) << A.s) + lo0 + (e & ((1u << A.tb) - 1));
-          gl_t w = A.tw[(size_t)gm << (A.d - 1 - lgS + A.tw_shift)];
-          gl_t u = v[j], t = gl_mul(v[j | (1 << lam)], w);
-          v[j] = gl_add(u, t);
-          v[j | (1 << lam)] = gl_sub(u, t);
-        }
+      if (s0 > 0) {
+        static_for<1, R>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          constexpr int e = brev_c(j, LOGR);
+          v[j] = gl_mul(v[j], tw[(size_t)(e - 1) * M + lo]);
+        });
       }
+      dft_regs<LOGR, 1, INV>(v);
     } else {
-#pragma unroll
-      for (int lam = LOGR - 1; lam >= 0; lam--) {
-        uint32_t beta = beta0 + lam;
-        uint32_t lgS = beta - A.tb + A.s;
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-          if (j & (1 << lam)) continue;
-          uint32_t e = base | ((uint32_t)j << beta0);
-          uint32_t gm = (((e & ((1u << beta) - 1)) >> A.tb) << A.s) + lo0 + (e & ((1u << A.tb) - 1));
-          gl_t w = A.tw[(size_t)gm << (A.d - 1 - lgS + A.tw_shift)];
-          gl_t u = v[j], x = v[j | (1 << lam)];
-          v[j] = gl_add(u, x);
-          v[j | (1 << lam)] = gl_mul(gl_sub(u, x), w);
-        }
+      dft_regs<LOGR, 0, INV>(v);
+      if (s0 > 0) {
+        static_for<1, R>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          constexpr int e = brev_c(j, LOGR);
+          v[j] = gl_mul(v[j], tw[(size_t)(e - 1) * M + lo]);
+        });
       }
     }
 #pragma unroll
@@ -93,57 +167,52 @@ __device__ __forceinline__ void round_regs(gl_t *lds, const PassArgs &A, uint32_
   }
 }
 
-template <int DIT>
+template <int DIT, bool INV>
 __device__ __forceinline__ void do_round(gl_t *lds, const PassArgs &A, uint32_t TB, uint32_t beta0, uint32_t logr,
-                                         uint32_t lo0) {
+                                         uint32_t lo0, const gl_t *tw) {
   switch (logr) {
-  case 4: round_regs<DIT, 4>(lds, A, TB, beta0, lo0); break;
-  case 3: round_regs<DIT, 3>(lds, A, TB, beta0, lo0); break;
-  case 2: round_regs<DIT, 2>(lds, A, TB, beta0, lo0); break;
-  default: round_regs<DIT, 1>(lds, A, TB, beta0, lo0); break;
+  case 4: round_regs<DIT, INV, 4>(lds, A, TB, beta0, lo0, tw); break;
+  case 3: round_regs<DIT, INV, 3>(lds, A, TB, beta0, lo0, tw); break;
+  case 2: round_regs<DIT, INV, 2>(lds, A, TB, beta0, lo0, tw); break;
+  default: round_regs<DIT, INV, 1>(lds, A, TB, beta0, lo0, tw); break;
   }
 }
 
 // grid: x = tile index within a column, y = column, z = coset
-template <int DIT>
+template <int DIT, bool INV>
 __global__ __launch_bounds__(256) void ntt_pass_kernel(PassArgs A) {
   extern __shared__ gl_t lds[];
   const uint32_t TB = A.a + A.tb;
   const uint32_t tile = blockIdx.x;
   const uint32_t col = blockIdx.y, coset = blockIdx.z;
   const size_t n = (size_t)1 << A.d;
-  // tile -> (hi, lo0): tiles enumerate lo-runs fastest
-  const uint32_t runs = 1u << (A.s - A.tb);  // number of lo-runs per hi block (s >= tb)
+  const uint32_t runs = 1u << (A.s - A.tb);  // lo-runs per hi block
   const uint32_t hi = tile / runs, lo0 = (tile % runs) << A.tb;
   const uint32_t hi_base = hi << (A.s + A.a);
-  const gl_t *src = A.src + ((size_t)(A.src_coset_stride_zero ? 0 : coset) * A.cols + col) * n;
+  const gl_t *src = A.src + ((size_t)(A.src_single ? 0 : coset) * A.cols + col) * n;
   gl_t *dst = A.dst + ((size_t)coset * A.cols + col) * n;
   const gl_t *scale = A.scale ? A.scale + (size_t)coset * n : nullptr;
   const uint32_t tsize = 1u << TB;
   for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
-    uint32_t g = gidx(e, hi_base, lo0, A.s, A.tb);
+    const uint32_t g = gidx(e, hi_base, lo0, A.s, A.tb);
     gl_t x = src[g];
     if (scale) x = gl_mul(x, scale[g]);
     lds[pidx(e)] = x;
   }
   __syncthreads();
-  // layers live on tile bits [tb, tb + a)
   if (DIT) {
-    uint32_t beta = A.tb, left = A.a;
-    while (left) {
-      uint32_t r = left >= 4 ? 4 : left;
-      do_round<1>(lds, A, TB, beta, r, lo0);
+    uint32_t beta = A.tb;
+    for (uint32_t i = 0; i < A.nrounds; i++) {
+      do_round<1, INV>(lds, A, TB, beta, A.r[i], lo0, A.ptw + A.tw_off[i]);
       __syncthreads();
-      beta += r;
-      left -= r;
+      beta += A.r[i];
     }
   } else {
-    uint32_t left = A.a;
-    while (left) {
-      uint32_t r = left >= 4 ? 4 : left;
-      do_round<0>(lds, A, TB, A.tb + left - r, r, lo0);
+    uint32_t beta = A.tb + A.a;
+    for (uint32_t i = A.nrounds; i-- > 0;) {
+      beta -= A.r[i];
+      do_round<0, INV>(lds, A, TB, beta, A.r[i], lo0, A.ptw + A.tw_off[i]);
       __syncthreads();
-      left -= r;
     }
   }
   const bool post = A.post != 1;
@@ -156,62 +225,138 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(PassArgs A) {
 
 static inline size_t lds_bytes(uint32_t TB) { return (((size_t)1 << TB) + ((size_t)1 << TB) / 16 + 1) * sizeof(gl_t); }
 
-// Plan: contiguous pass over the low `b` bits, strided passes over the rest.
-// DIF (natural -> bitrev) runs the strided passes first; DIT runs them last.
-void ntt_batch(hipStream_t st, int dit, const gl_t *src, gl_t *dst, uint32_t d, uint32_t cols, uint32_t cosets,
-               const gl_t *tw, uint32_t tw_shift, const gl_t *scale, gl_t post, bool src_per_coset) {
-  if (cols == 0) return;
-  const uint32_t TBMAX = 12;
-  struct P { uint32_t s, a, tb; };
-  P passes[8];
-  int np = 0;
-  uint32_t b = d < TBMAX ? d : TBMAX;
-  if (d == 0) {  // size-1 transform: copy (+scale)
-    b = 0;
-  }
-  // contiguous pass: s = 0, a = b, tb = 0
-  // strided passes: split the remaining d - b high bits into chunks of <= 8
-  P strided[8];
-  int ns = 0;
-  uint32_t rem = d - b, s = b;
-  while (rem) {
-    uint32_t a = rem > 8 ? 8 : rem;
-    uint32_t tb = TBMAX - a;
-    if (tb > s) tb = s;
-    strided[ns++] = P{s, a, tb};
-    s += a;
-    rem -= a;
-  }
-  if (dit) {
-    passes[np++] = P{0, b, 0};
-    for (int i = 0; i < ns; i++) passes[np++] = strided[i];
+// ---- plan -----------------------------------------------------------------------
+// packed twiddles of one round: T[(e-1) * M + lo] = root_n^((lo * e) << (d - s0 - r)), e in [1, 2^r)
+__global__ void round_table_kernel(gl_t *out, gl_t root_n, uint32_t d, uint32_t s0, uint32_t r) {
+  const uint32_t M = 1u << s0, cnt = ((1u << r) - 1) * M;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  const uint32_t e = i / M + 1, lo = i % M;
+  out[i] = gl_pow(root_n, ((uint64_t)lo * e) << (d - s0 - r));
+}
+
+static void split_rounds(uint32_t a, std::vector<uint32_t> &r) {
+  // rounds of 4 layers, remainder fixed up without ever using a lone 1 when avoidable
+  r.clear();
+  uint32_t q = a / 4, rem = a % 4;
+  if (rem == 1 && q >= 1) {  // 4 + 1 -> 3 + 2
+    for (uint32_t i = 0; i + 1 < q; i++) r.push_back(4);
+    r.push_back(3);
+    r.push_back(2);
   } else {
-    for (int i = ns - 1; i >= 0; i--) passes[np++] = strided[i];
-    passes[np++] = P{0, b, 0};
+    for (uint32_t i = 0; i < q; i++) r.push_back(4);
+    if (rem) r.push_back(rem);
   }
-  for (int i = 0; i < np; i++) {
+}
+
+NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse) {
+  NttPlan *p = new NttPlan();
+  p->d = d;
+  p->dit = dit;
+  p->inverse = inverse;
+  const uint32_t TBMAX = 12;
+  const uint32_t b = d < TBMAX ? d : TBMAX;
+  struct P { uint32_t s, a, tb; };
+  std::vector<P> strided;
+  {
+    uint32_t rem = d - b, s = b;
+    uint32_t npass = rem == 0 ? 0 : (rem <= 8 ? 1 : 2);
+    for (uint32_t i = 0; i < npass; i++) {
+      uint32_t a = (npass == 1) ? rem : (i == 0 ? (rem + 1) / 2 : rem / 2);
+      uint32_t tb = TBMAX - a;
+      if (tb > s) tb = s;
+      strided.push_back(P{s, a, tb});
+      s += a;
+    }
+  }
+  std::vector<P> passes;
+  if (dit) {
+    passes.push_back(P{0, b, 0});
+    for (auto &x : strided) passes.push_back(x);
+  } else {
+    for (size_t i = strided.size(); i-- > 0;) passes.push_back(strided[i]);
+    passes.push_back(P{0, b, 0});
+  }
+  // table layout
+  size_t total = 0;
+  std::vector<uint32_t> rr;
+  for (auto &ps : passes) {
+    NttPass np;
+    np.s = ps.s; np.a = ps.a; np.tb = ps.tb;
+    split_rounds(ps.a, rr);
+    np.nrounds = (uint32_t)rr.size();
+    uint32_t beta = ps.tb;
+    for (uint32_t i = 0; i < np.nrounds; i++) {
+      np.r[i] = rr[i];
+      np.tw_off[i] = (uint32_t)total;
+      uint32_t s0 = beta - ps.tb + ps.s;
+      if (s0 > 0) total += (size_t)((1u << rr[i]) - 1) << s0;
+      beta += rr[i];
+    }
+    p->passes.push_back(np);
+  }
+  p->table_len = total;
+  if (total) {
+    if (hipMalloc((void **)&p->ptw, total * sizeof(gl_t)) != hipSuccess) {
+      delete p;
+      return nullptr;
+    }
+    gl_t root = gl_root(d);
+    if (inverse) root = gl_inv(root);
+    for (auto &np : p->passes) {
+      uint32_t beta = np.tb;
+      for (uint32_t i = 0; i < np.nrounds; i++) {
+        uint32_t s0 = beta - np.tb + np.s;
+        if (s0 > 0) {
+          uint32_t cnt = ((1u << np.r[i]) - 1) << s0;
+          hipLaunchKernelGGL(round_table_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, p->ptw + np.tw_off[i], root, d,
+                             s0, np.r[i]);
+        }
+        beta += np.r[i];
+      }
+    }
+  }
+  return p;
+}
+void ntt_plan_destroy(NttPlan *p) {
+  if (!p) return;
+  if (p->ptw) (void)hipFree(p->ptw);
+  delete p;
+}
+
+void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
+               const gl_t *scale, gl_t post, bool src_per_coset) {
+  if (cols == 0) return;
+  const uint32_t d = plan->d;
+  const size_t np = plan->passes.size();
+  for (size_t i = 0; i < np; i++) {
+    const NttPass &ps = plan->passes[i];
     PassArgs A;
     A.src = (i == 0) ? src : dst;
     A.dst = dst;
-    A.tw = tw;
-    A.scale = (i == 0 && dit) ? scale : nullptr;
+    A.ptw = plan->ptw;
+    A.scale = (i == 0 && plan->dit) ? scale : nullptr;
     A.post = (i == np - 1) ? post : 1;
     A.d = d;
-    A.s = passes[i].s;
-    A.a = passes[i].a;
-    A.tb = passes[i].tb;
-    A.tw_shift = tw_shift;
+    A.s = ps.s; A.a = ps.a; A.tb = ps.tb;
     A.cols = cols;
-    A.src_coset_stride_zero = (i == 0 && !src_per_coset) ? 1 : 0;
-    uint32_t TB = A.a + A.tb;
-    uint32_t tiles = 1u << (d - TB);
+    A.src_single = (i == 0 && !src_per_coset) ? 1 : 0;
+    A.nrounds = ps.nrounds;
+    for (int k = 0; k < MAX_ROUNDS; k++) { A.r[k] = ps.r[k]; A.tw_off[k] = ps.tw_off[k]; }
+    const uint32_t TB = A.a + A.tb;
+    const uint32_t tiles = 1u << (d - TB);
     dim3 grid(tiles, cols, cosets);
-    uint32_t threads = TB >= 8 ? 256 : 64;
-    ProfScope ps(dit ? "ntt_pass_kernel<1>" : "ntt_pass_kernel<0>", 16.0 * ((double)cols * cosets * ((size_t)1 << d)));
-    if (dit)
-      hipLaunchKernelGGL(ntt_pass_kernel<1>, grid, dim3(threads), lds_bytes(TB), st, A);
-    else
-      hipLaunchKernelGGL(ntt_pass_kernel<0>, grid, dim3(threads), lds_bytes(TB), st, A);
+    const uint32_t threads = TB >= 8 ? 256 : 64;
+    const double bytes = 16.0 * ((double)cols * cosets * ((size_t)1 << d));
+    if (plan->dit) {
+      ProfScope psx(plan->inverse ? "ntt_pass_kernel<1,1>" : "ntt_pass_kernel<1,0>", bytes);
+      if (plan->inverse) hipLaunchKernelGGL((ntt_pass_kernel<1, true>), grid, dim3(threads), lds_bytes(TB), st, A);
+      else hipLaunchKernelGGL((ntt_pass_kernel<1, false>), grid, dim3(threads), lds_bytes(TB), st, A);
+    } else {
+      ProfScope psx(plan->inverse ? "ntt_pass_kernel<0,1>" : "ntt_pass_kernel<0,0>", bytes);
+      if (plan->inverse) hipLaunchKernelGGL((ntt_pass_kernel<0, true>), grid, dim3(threads), lds_bytes(TB), st, A);
+      else hipLaunchKernelGGL((ntt_pass_kernel<0, false>), grid, dim3(threads), lds_bytes(TB), st, A);
+    }
   }
 }
 

@@ -174,6 +174,8 @@ struct p2gpu_circuit {
   // tables
   DBuf<gl_t> tw_fwd, tw_inv, scale, inv_scale, d_kis, d_sigmas, fri_scale, qconst;
   DBuf<GateDesc> d_gates;
+  NttPlan *plan_inv = nullptr, *plan_fwd = nullptr;  // size n: values->coeffs (DIF, w^-1), coeffs->values (DIT)
+  std::vector<NttPlan *> fri_plans;                   // DIT plans of the FRI step sizes
   // oracles
   Batch cs, wires, zp, quot;
   dig_t circuit_digest;
@@ -257,7 +259,13 @@ int tree_alloc(Batch &b, uint32_t C, size_t m0, size_t cap_per) {
 int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
   const uint32_t C = c->C;
   size_t m = m0;
+  const size_t cap_target = ((size_t)1 << c->cap_h) >> c->rate_bits;
   for (size_t l = 1; l < b.level_off.size(); l++) {
+    if (m <= 4096) {  // the rest of the tree in one launch
+      merkle_tail(c->stream, b.dig.p + b.level_off[l - 1], C, (uint32_t)m, (uint32_t)cap_target);
+      m = cap_target;
+      break;
+    }
     merkle_level(c->stream, b.dig.p + b.level_off[l - 1], b.dig.p + b.level_off[l], C, (uint32_t)m);
     m >>= 1;
   }
@@ -277,7 +285,7 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
 // coefficients (bit-reversed storage) -> LDE on the 2^rate_bits cosets -> leaf digests -> tree
 int batch_commit_from_coeffs(p2gpu_circuit *c, Batch &b) {
   {
-    ntt_batch(c->stream, 1, b.coeffs.p, b.lde.p, c->d, b.cols, c->C, c->tw_fwd.p, 0, c->scale.p, 1, false);
+    ntt_batch(c->stream, c->plan_fwd, b.coeffs.p, b.lde.p, b.cols, c->C, c->scale.p, 1, false);
   }
   {
     hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, c->C, b.dig.p);
@@ -288,7 +296,7 @@ int batch_commit_from_coeffs(p2gpu_circuit *c, Batch &b) {
 int batch_commit_from_values(p2gpu_circuit *c, Batch &b, const gl_t *vals_dev) {
   {
     gl_t ninv = gl_inv((gl_t)c->n);
-    ntt_batch(c->stream, 0, vals_dev, b.coeffs.p, c->d, b.cols, 1, c->tw_inv.p, 0, nullptr, ninv, false);
+    ntt_batch(c->stream, c->plan_inv, vals_dev, b.coeffs.p, b.cols, 1, nullptr, ninv, false);
   }
   TRACE(c, "  inverse ntt");
   return batch_commit_from_coeffs(c, b);
@@ -429,7 +437,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     TRACE(c, "quotient_eval");
     // coset_ifft of size N = per-coset inverse transforms + cross-coset butterflies
     {
-      ntt_batch(st, 0, c->qvals.p, c->qtmp.p, d, K * C, 1, c->tw_inv.p, 0, nullptr, q.n_inv, false);
+      ntt_batch(st, c->plan_inv, c->qvals.p, c->qtmp.p, K * C, 1, nullptr, q.n_inv, false);
     }
     {
       quotient_chunks(st, c->qtmp.p, c->inv_scale.p, c->quot.coeffs.p, d, K, c->rate_bits, gl_inv(wC), gl_inv(gn),
@@ -509,15 +517,15 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
       reduce_columns(st, c->zp.coeffs.p, K, d, c->ext_apow.p, 0, F1, false);
     }
     {
-      ntt_batch(st, 1, c->f01.p, c->f01v.p, d, 4, 1, c->tw_fwd.p, 0, nullptr, 1, false);
+      ntt_batch(st, c->plan_fwd, c->f01.p, c->f01v.p, 4, 1, nullptr, 1, false);
     }
     fri_quotient_values(st, c->f01v.p, c->f01v.p + 2 * n, d, c->tw_fwd.p, 0, zeta, gzeta, f0z, f1z, ext_pow(alpha, K),
                         c->fv.p);
     {
-      ntt_batch(st, 0, c->fv.p, c->fri_coef[0].p, d, 2, 1, c->tw_inv.p, 0, nullptr, gl_inv((gl_t)n), false);
+      ntt_batch(st, c->plan_inv, c->fv.p, c->fri_coef[0].p, 2, 1, nullptr, gl_inv((gl_t)n), false);
     }
     if (c->n_steps > 0) {  // no reduction step (degree <= 2^5): the values are never committed
-      ntt_batch(st, 1, c->fri_coef[0].p, c->fri_vals[0].p, d, 2, C, c->tw_fwd.p, 0, c->scale.p, 1, false);
+      ntt_batch(st, c->plan_fwd, c->fri_coef[0].p, c->fri_vals[0].p, 2, C, c->scale.p, 1, false);
     }
   }
   TRACE(c, "fri final poly lde");
@@ -539,8 +547,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     ds -= ab;
     if (s + 1 < c->n_steps) {
       fill_coset_scale(st, c->fri_scale.p, shift, gl_root(ds + c->rate_bits), ds, C, 1);
-      ntt_batch(st, 1, c->fri_coef[s + 1].p, c->fri_vals[s + 1].p, ds, 2, C, c->tw_fwd.p, d - ds, c->fri_scale.p, 1,
-                false);
+      ntt_batch(st, c->fri_plans[s + 1], c->fri_coef[s + 1].p, c->fri_vals[s + 1].p, 2, C, c->fri_scale.p, 1, false);
     }
   }
   const size_t n_final = (size_t)1 << ds;
@@ -563,8 +570,9 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     gl_t inter[12];
     memcpy(inter, ch.state, sizeof inter);
     for (int i = 0; i < ch.n_in; i++) inter[i] = ch.in[i];
-    const uint64_t batch = 1ull << 20;
-    for (uint64_t base = 0;; base += batch) {
+    // expected minimum witness ~2^pow_bits: start with 2^(pow_bits+1) candidates, then double
+    uint64_t batch = 1ull << (c->pow_bits + 1 < 20 ? c->pow_bits + 1 : 20);
+    for (uint64_t base = 0;; base += batch, batch = batch < (1ull << 22) ? batch * 2 : batch) {
       unsigned long long init = ~0ull;
       HIP_TRY(hipMemcpyAsync(c->pow_result.p, &init, 8, hipMemcpyHostToDevice, st));
       {
@@ -713,6 +721,12 @@ void circuit_release(p2gpu_circuit *c) {
   for (auto &b : c->fri_vals) b.release();
   for (auto &b : c->fri_trees) b.release();
   c->pow_result.release(); c->gather_ptrs.release(); c->gather_out.release();
+  ntt_plan_destroy(c->plan_inv);
+  ntt_plan_destroy(c->plan_fwd);
+  for (auto *p : c->fri_plans)
+    if (p != c->plan_fwd) ntt_plan_destroy(p);
+  c->plan_inv = c->plan_fwd = nullptr;
+  c->fri_plans.clear();
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
 }
@@ -906,6 +920,9 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   CK(c->d_sigmas.alloc((size_t)c->R * n), "alloc sigmas");
   CK(c->d_gates.alloc(c->num_gates ? c->num_gates : 1), "alloc gates");
   gl_t wn = gl_root(d), wN = gl_root(d + c->rate_bits);
+  c->plan_inv = ntt_plan_create(st, d, 0, true);
+  c->plan_fwd = ntt_plan_create(st, d, 1, false);
+  if (!c->plan_inv || !c->plan_fwd) return fail(P2GPU_E_DEVICE, "ntt plan allocation failed");
   fill_powers(st, c->tw_fwd.p, wn, (uint32_t)half);
   fill_powers(st, c->tw_inv.p, gl_inv(wn), (uint32_t)half);
   fill_coset_scale(st, c->scale.p, GL_GEN, wN, d, C, 1);
@@ -969,6 +986,8 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     uint32_t ds = d;
     const size_t cap_per = ((size_t)1 << c->cap_h) >> c->rate_bits;
     for (uint32_t s = 0; s <= c->n_steps; s++) {
+      c->fri_plans.push_back(s == 0 ? c->plan_fwd : ntt_plan_create(st, ds, 1, false));
+      if (!c->fri_plans.back()) return fail(P2GPU_E_DEVICE, "ntt plan allocation failed");
       CK(c->fri_coef[s].alloc((size_t)2 << ds), "alloc fri coef");
       if (s < c->n_steps) {
         CK(c->fri_vals[s].alloc((size_t)2 * C << ds), "alloc fri vals");
@@ -1002,7 +1021,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     CK(hipMemcpyAsync(stage + (size_t)c->NC * n, c->d_sigmas.p, 8 * (size_t)c->R * n, hipMemcpyDeviceToDevice, st), "copy sigmas");
     {
       gl_t ninv = gl_inv((gl_t)n);
-      ntt_batch(st, 0, stage, c->cs.coeffs.p, d, ncs, 1, c->tw_inv.p, 0, nullptr, ninv, false);
+      ntt_batch(st, c->plan_inv, stage, c->cs.coeffs.p, ncs, 1, nullptr, ninv, false);
     }
     if (int rc = batch_commit_from_coeffs(c, c->cs)) {
       std::string keep = g_err;
@@ -1119,11 +1138,15 @@ int p2gpu_ifft_batch(const uint64_t *vals, size_t ncols, unsigned d, uint64_t *c
   gl_t *a = S.alloc<gl_t>(ncols * n), *b = S.alloc<gl_t>(ncols * n), *tw = S.alloc<gl_t>(half);
   if (!a || !b || !tw) { set_err("hipMalloc failed"); return P2GPU_E_DEVICE; }
   HIP_TRY(hipMemcpyAsync(a, vals, 8 * ncols * n, hipMemcpyHostToDevice, S.st));
-  fill_powers(S.st, tw, gl_inv(gl_root(d)), (uint32_t)half);
-  ntt_batch(S.st, 0, a, b, d, (uint32_t)ncols, 1, tw, 0, nullptr, gl_inv((gl_t)n), false);
+  NttPlan *plan = ntt_plan_create(S.st, d, 0, true);
+  if (!plan) { set_err("hipMalloc failed"); return P2GPU_E_DEVICE; }
+  ntt_batch(S.st, plan, a, b, (uint32_t)ncols, 1, nullptr, gl_inv((gl_t)n), false);
   bitrev_cols(S.st, b, a, d, (uint32_t)ncols);  // natural-order coefficients for the caller
-  HIP_TRY(hipMemcpyAsync(coeffs_out, a, 8 * ncols * n, hipMemcpyDeviceToHost, S.st));
-  HIP_TRY(hipStreamSynchronize(S.st));
+  hipError_t e1 = hipMemcpyAsync(coeffs_out, a, 8 * ncols * n, hipMemcpyDeviceToHost, S.st);
+  hipError_t e2 = hipStreamSynchronize(S.st);
+  ntt_plan_destroy(plan);
+  HIP_TRY(e1);
+  HIP_TRY(e2);
   return P2GPU_OK;
 }
 
@@ -1139,13 +1162,17 @@ int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned r
   if (!a || !b || !tw || !scale || !lde) { set_err("hipMalloc failed"); return P2GPU_E_DEVICE; }
   HIP_TRY(hipMemcpyAsync(a, coeffs, 8 * ncols * n, hipMemcpyHostToDevice, S.st));
   bitrev_cols(S.st, a, b, d, (uint32_t)ncols);
-  fill_powers(S.st, tw, gl_root(d), (uint32_t)half);
+  NttPlan *plan = ntt_plan_create(S.st, d, 1, false);
+  if (!plan) { set_err("hipMalloc failed"); return P2GPU_E_DEVICE; }
   fill_coset_scale(S.st, scale, GL_GEN, gl_root(d + rate_bits), d, C, 1);
-  ntt_batch(S.st, 1, b, lde, d, (uint32_t)ncols, C, tw, 0, scale, 1, false);
+  ntt_batch(S.st, plan, b, lde, (uint32_t)ncols, C, scale, 1, false);
   // [C][cols][n] -> natural order per column: out[col][C*k + r]
   std::vector<gl_t> tmp(C * ncols * n);
-  HIP_TRY(hipMemcpyAsync(tmp.data(), lde, 8 * tmp.size(), hipMemcpyDeviceToHost, S.st));
-  HIP_TRY(hipStreamSynchronize(S.st));
+  hipError_t e1 = hipMemcpyAsync(tmp.data(), lde, 8 * tmp.size(), hipMemcpyDeviceToHost, S.st);
+  hipError_t e2 = hipStreamSynchronize(S.st);
+  ntt_plan_destroy(plan);
+  HIP_TRY(e1);
+  HIP_TRY(e2);
   for (uint32_t r = 0; r < C; r++)
     for (size_t col = 0; col < ncols; col++)
       for (size_t k = 0; k < n; k++) lde_out[col * C * n + C * k + r] = tmp[((size_t)r * ncols + col) * n + k];
@@ -1188,8 +1215,13 @@ int p2gpu_commit_values(const uint64_t *vals, size_t ncols, unsigned d, unsigned
       break;
     }
     if ((rc = batch_alloc(c, c->wires, (uint32_t)ncols))) break;
-    fill_powers(c->stream, c->tw_fwd.p, gl_root(d), (uint32_t)half);
-    fill_powers(c->stream, c->tw_inv.p, gl_inv(gl_root(d)), (uint32_t)half);
+    c->plan_inv = ntt_plan_create(c->stream, d, 0, true);
+    c->plan_fwd = ntt_plan_create(c->stream, d, 1, false);
+    if (!c->plan_inv || !c->plan_fwd) {
+      set_err("hipMalloc failed");
+      rc = P2GPU_E_DEVICE;
+      break;
+    }
     fill_coset_scale(c->stream, c->scale.p, GL_GEN, gl_root(d + rate_bits), d, c->C, 1);
     if (hipMemcpyAsync(c->wires_vals.p, vals, 8 * ncols * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
       set_err("copy failed");

@@ -178,11 +178,14 @@ __device__ __forceinline__ void do_round(gl_t *lds, const PassArgs &A, uint32_t 
   }
 }
 
-// grid: x = tile index within a column, y = column, z = coset
-template <int DIT, bool INV>
+// grid: x = tile index within a column, y = column, z = coset.
+// TBC = 12: the full 2^12-element tile with 256 lanes -- the global loads/stores of a lane are 16
+// independent accesses issued back to back (compile-time trip count) so their latencies overlap;
+// TBC = 0: any smaller tile (small transforms), runtime loops.
+template <int DIT, bool INV, int TBC>
 __global__ __launch_bounds__(256) void ntt_pass_kernel(PassArgs A) {
   extern __shared__ gl_t lds[];
-  const uint32_t TB = A.a + A.tb;
+  const uint32_t TB = TBC ? TBC : A.a + A.tb;
   const uint32_t tile = blockIdx.x;
   const uint32_t col = blockIdx.y, coset = blockIdx.z;
   const size_t n = (size_t)1 << A.d;
@@ -193,11 +196,31 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(PassArgs A) {
   gl_t *dst = A.dst + ((size_t)coset * A.cols + col) * n;
   const gl_t *scale = A.scale ? A.scale + (size_t)coset * n : nullptr;
   const uint32_t tsize = 1u << TB;
-  for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
-    const uint32_t g = gidx(e, hi_base, lo0, A.s, A.tb);
-    gl_t x = src[g];
-    if (scale) x = gl_mul(x, scale[g]);
-    lds[pidx(e)] = x;
+  if constexpr (TBC != 0) {
+    constexpr int PER = (1 << TBC) / 256;
+    gl_t x[PER];
+    uint32_t g[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      g[i] = gidx(threadIdx.x + i * 256, hi_base, lo0, A.s, A.tb);
+      x[i] = src[g[i]];
+    }
+    if (scale) {
+      gl_t sc[PER];
+#pragma unroll
+      for (int i = 0; i < PER; i++) sc[i] = scale[g[i]];
+#pragma unroll
+      for (int i = 0; i < PER; i++) x[i] = gl_mul(x[i], sc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++) lds[pidx(threadIdx.x + i * 256)] = x[i];
+  } else {
+    for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
+      const uint32_t g = gidx(e, hi_base, lo0, A.s, A.tb);
+      gl_t x = src[g];
+      if (scale) x = gl_mul(x, scale[g]);
+      lds[pidx(e)] = x;
+    }
   }
   __syncthreads();
   if (DIT) {
@@ -216,10 +239,23 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(PassArgs A) {
     }
   }
   const bool post = A.post != 1;
-  for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
-    gl_t x = lds[pidx(e)];
-    if (post) x = gl_mul(x, A.post);
-    dst[gidx(e, hi_base, lo0, A.s, A.tb)] = x;
+  if constexpr (TBC != 0) {
+    constexpr int PER = (1 << TBC) / 256;
+    gl_t x[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) x[i] = lds[pidx(threadIdx.x + i * 256)];
+    if (post) {
+#pragma unroll
+      for (int i = 0; i < PER; i++) x[i] = gl_mul(x[i], A.post);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++) dst[gidx(threadIdx.x + i * 256, hi_base, lo0, A.s, A.tb)] = x[i];
+  } else {
+    for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
+      gl_t x = lds[pidx(e)];
+      if (post) x = gl_mul(x, A.post);
+      dst[gidx(e, hi_base, lo0, A.s, A.tb)] = x;
+    }
   }
 }
 
@@ -348,15 +384,23 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     dim3 grid(tiles, cols, cosets);
     const uint32_t threads = TB >= 8 ? 256 : 64;
     const double bytes = 16.0 * ((double)cols * cosets * ((size_t)1 << d));
+    const char *name = plan->dit ? (plan->inverse ? "ntt_pass_kernel<1,1>" : "ntt_pass_kernel<1,0>")
+                                 : (plan->inverse ? "ntt_pass_kernel<0,1>" : "ntt_pass_kernel<0,0>");
+    ProfScope psx(name, bytes);
+    const size_t lb = lds_bytes(TB);
+#define P2_LAUNCH(DITV, INVV)                                                                                \
+  do {                                                                                                       \
+    if (TB == 12) hipLaunchKernelGGL((ntt_pass_kernel<DITV, INVV, 12>), grid, dim3(256), lb, st, A);          \
+    else hipLaunchKernelGGL((ntt_pass_kernel<DITV, INVV, 0>), grid, dim3(threads), lb, st, A);               \
+  } while (0)
     if (plan->dit) {
-      ProfScope psx(plan->inverse ? "ntt_pass_kernel<1,1>" : "ntt_pass_kernel<1,0>", bytes);
-      if (plan->inverse) hipLaunchKernelGGL((ntt_pass_kernel<1, true>), grid, dim3(threads), lds_bytes(TB), st, A);
-      else hipLaunchKernelGGL((ntt_pass_kernel<1, false>), grid, dim3(threads), lds_bytes(TB), st, A);
+      if (plan->inverse) P2_LAUNCH(1, true);
+      else P2_LAUNCH(1, false);
     } else {
-      ProfScope psx(plan->inverse ? "ntt_pass_kernel<0,1>" : "ntt_pass_kernel<0,0>", bytes);
-      if (plan->inverse) hipLaunchKernelGGL((ntt_pass_kernel<0, true>), grid, dim3(threads), lds_bytes(TB), st, A);
-      else hipLaunchKernelGGL((ntt_pass_kernel<0, false>), grid, dim3(threads), lds_bytes(TB), st, A);
+      if (plan->inverse) P2_LAUNCH(0, true);
+      else P2_LAUNCH(0, false);
     }
+#undef P2_LAUNCH
   }
 }
 

@@ -201,6 +201,7 @@ __device__ __forceinline__ void eval_gate(const GateDesc &g, WF W, CF LC, const 
     break;
   case G_ARITHMETIC: {
     const gl_t c0 = LC(0), c1 = LC(1);
+#pragma unroll 4
     for (uint32_t i = 0; i < g.p[0]; i++) {
       gl_t m0 = W(4 * i), m1 = W(4 * i + 1), ad = W(4 * i + 2), o = W(4 * i + 3);
       gl_t comp = gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(ad, c1));
@@ -211,8 +212,10 @@ __device__ __forceinline__ void eval_gate(const GateDesc &g, WF W, CF LC, const 
   case G_BASE_SUM: {
     const uint32_t B = g.p[0], L = g.p[1];
     gl_t acc = 0;
+#pragma unroll 8
     for (uint32_t i = L; i-- > 0;) acc = gl_add(gl_mul_small(acc, B), W(1 + i));
     out.emit(gl_sub(acc, W(0)));
+#pragma unroll 8
     for (uint32_t i = 0; i < L; i++) out.emit(range_product(W(1 + i), B));
     break;
   }
@@ -262,6 +265,7 @@ __device__ __forceinline__ void eval_gate(const GateDesc &g, WF W, CF LC, const 
       gl_t combined = gl_add(gl_mul(hi, 1ULL << 32), lo);
       out.emit(gl_sub(combined, computed));
       gl_t cl = 0, ch = 0;
+#pragma unroll 8
       for (uint32_t j = 32; j-- > 0;) {
         gl_t limb = W(6 * ops + 32 * i + j);
         out.emit(range4(limb));
@@ -283,6 +287,7 @@ __device__ __forceinline__ void eval_gate(const GateDesc &g, WF W, CF LC, const 
       gl_t combined = gl_add(gl_mul(oc, 1ULL << 32), res);
       out.emit(gl_sub(combined, computed));
       gl_t cr = 0, cc = 0;
+#pragma unroll 6
       for (uint32_t j = 18; j-- > 0;) {
         gl_t limb = W((na + 3) * ops + 18 * i + j);
         out.emit(range4(limb));
@@ -301,6 +306,7 @@ __device__ __forceinline__ void eval_gate(const GateDesc &g, WF W, CF LC, const 
       gl_t init = gl_sub(gl_sub(x, y), bin);
       out.emit(gl_sub(res, gl_add(init, gl_mul(bout, 1ULL << 32))));
       gl_t comb = 0;
+#pragma unroll 8
       for (uint32_t j = 16; j-- > 0;) {
         gl_t limb = W(5 * ops + 16 * i + j);
         out.emit(range4(limb));
@@ -315,8 +321,10 @@ __device__ __forceinline__ void eval_gate(const GateDesc &g, WF W, CF LC, const 
     const uint32_t nl = g.p[0];
     for (uint32_t i = 0; i < nl; i++) {
       gl_t sum = 0;
+#pragma unroll 8
       for (uint32_t j = 16; j-- > 0;) sum = gl_add(gl_mul_small(sum, 4), W(nl + 16 * i + j));
       out.emit(gl_sub(sum, W(i)));
+#pragma unroll 8
       for (uint32_t j = 0; j < 16; j++) out.emit(range4(W(nl + 16 * i + j)));
     }
     break;
@@ -361,7 +369,7 @@ __device__ __forceinline__ void eval_gate(const GateDesc &g, WF W, CF LC, const 
 }
 
 // grid: x = k blocks, y = coset
-__global__ __launch_bounds__(256) void quotient_kernel(QuotArgs a) {
+__global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
   const uint32_t n = 1u << a.d;
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = blockIdx.y;
@@ -387,6 +395,7 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotArgs a) {
     const uint32_t t_base = out.t;
     for (uint32_t m = 0; m < a.nchunks; m++) {
       gl_t n0 = 1, d0 = 1, n1 = 1, d1 = 1;
+#pragma unroll 8
       for (uint32_t j = m * a.QF; j < (m + 1) * a.QF && j < a.R; j++) {
         const gl_t wv = wl[(size_t)j * n];
         const gl_t sg = cs[(size_t)(a.NC + j) * n];

@@ -68,10 +68,14 @@ def cpu_baseline(pkg, d_sample, d_target, mix):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--degree-bits", type=int, default=17)
     ap.add_argument("--mix", default="sha")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="independent proofs in flight per GPU (separate circuit handles / HIP streams, one host "
+                         "thread each): hides the latency-bound Merkle-tree tails and host round trips of one proof "
+                         "behind the kernels of another; 1 = strictly one proof at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bits", type=int, default=14)
     args = ap.parse_args()
@@ -97,7 +101,8 @@ def main():
     d, mix = args.degree_bits, args.mix
     # every rank proves its own witness of the same circuit shape (independent proofs)
     blob, wires = pkg.make_circuit(d, mix, seed=1 + rank)
-    cd = pkg.CircuitData(blob)
+    S = max(1, min(args.in_flight, args.steps))
+    cds = [pkg.CircuitData(blob) for _ in range(S)]
     wires_dev = torch.from_numpy(wires.view(np.int64)).cuda()
     torch.cuda.synchronize()
 
@@ -106,23 +111,55 @@ def main():
         if world > 1:
             dist.barrier()
 
-    proof = None
-    for _ in range(args.warmup):
-        proof = cd.prove(wires_dev)
-    cd.set("profile", 1)  # per-launch HIP events on the library's stream, over the timed region
+    import threading
+
+    def run(n_proofs, collect=None):
+        """n_proofs proofs over the S handles (thread i proves every S-th proof)."""
+        def work(i):
+            last = None
+            for _ in range(i, n_proofs, S):
+                last = cds[i].prove(wires_dev)
+                if collect is not None:
+                    collect.append(last.timings)
+            results[i] = last
+        results = [None] * S
+        th = [threading.Thread(target=work, args=(i,)) for i in range(S)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return next(r for r in results if r is not None)
+
+    proof = run(max(args.warmup, S))
+    for cd in cds:
+        cd.set("profile", 1)  # per-launch HIP events on each handle's stream, over the timed region
     barrier()
     t0 = time.perf_counter()
-    phase = {}
-    for _ in range(args.steps):
-        proof = cd.prove(wires_dev)
-        for k, v in proof.timings.items():
-            if k.endswith("_ms"):
-                phase[k] = phase.get(k, 0.0) + v
+    tms = []
+    proof = run(args.steps, tms)
     barrier()
     dt = time.perf_counter() - t0
     dt = pkg.parallel.max_over_ranks(dt)
-    stats = cd.kernel_stats()
-    cd.set("profile", 0)
+    stats = {}
+    for cd in cds:
+        for k, v in cd.kernel_stats().items():
+            a = stats.setdefault(k, {"ms": 0.0, "bytes": 0.0, "launches": 0})
+            for f in a:
+                a[f] += v[f]
+        cd.set("profile", 0)
+    phase = {}
+    for t in tms:
+        for k, v in t.items():
+            if k.endswith("_ms"):
+                phase[k] = phase.get(k, 0.0) + v
+    # single-proof latency (nothing else in flight), measured after the timed region
+    cds[0].prove(wires_dev)
+    torch.cuda.synchronize()
+    tl = time.perf_counter()
+    for _ in range(3):
+        cds[0].prove(wires_dev)
+    latency_ms = (time.perf_counter() - tl) / 3 * 1e3
+    cd = cds[0]
 
     if rank == 0:
         total_proofs = world * args.steps
@@ -147,7 +184,8 @@ def main():
                 "workload": f"synth(d={d},{mix}): {1 << d} gates -> 2^{d + 3} LDE rows, 234 wires / 80 routed, "
                             f"KeccakGoldilocksConfig, rate 8, cap 2^4, 28 queries, 16 PoW bits (BASELINE configs[2] shape)",
                 "degree_bits": d, "lde_rows": 1 << (d + 3), "mix": mix,
-                "parallelism": f"replicas x{world} (one proof per GPU, no data-path collective)",
+                "parallelism": f"replicas x{world} (independent proofs per GPU, no data-path collective), "
+                               f"{S} proofs in flight per GPU",
                 "proof_bytes": len(proof),
                 "witness": "resident in HBM (p2gpu_prove_dev); proof bytes returned to host",
             },
@@ -164,6 +202,8 @@ def main():
                 "launches_per_proof": st["launches"] / args.steps,
                 "algorithmic_bytes_per_launch": st["bytes"] / st["launches"],
             },
+            "latency_ms_single_proof": latency_ms,
+            "in_flight_per_gpu": S,
             "phase_ms": {k: v / args.steps for k, v in sorted(phase.items())},
             "kernel_ms_per_proof": {k: round(v["ms"] / args.steps, 4) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])},
             "device": pkg.device_info()["name"],
@@ -171,7 +211,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, min(args.cpu_sample_bits, d), d, mix)
         print(json.dumps(out), flush=True)
-    cd.close()
+    for c_ in cds:
+        c_.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

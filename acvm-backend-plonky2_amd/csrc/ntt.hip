@@ -384,8 +384,14 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     dim3 grid(tiles, cols, cosets);
     const uint32_t threads = TB >= 8 ? 256 : 64;
     const double bytes = 16.0 * ((double)cols * cosets * ((size_t)1 << d));
-    const char *name = plan->dit ? (plan->inverse ? "ntt_pass_kernel<1,1>" : "ntt_pass_kernel<1,0>")
-                                 : (plan->inverse ? "ntt_pass_kernel<0,1>" : "ntt_pass_kernel<0,0>");
+    // same spelling as rocprofv3's demangled kernel names, so the bench line and profiles/ agree
+    const char *name;
+    if (TB == 12)
+      name = plan->dit ? (plan->inverse ? "ntt_pass_kernel<1, true, 12>" : "ntt_pass_kernel<1, false, 12>")
+                       : (plan->inverse ? "ntt_pass_kernel<0, true, 12>" : "ntt_pass_kernel<0, false, 12>");
+    else
+      name = plan->dit ? (plan->inverse ? "ntt_pass_kernel<1, true, 0>" : "ntt_pass_kernel<1, false, 0>")
+                       : (plan->inverse ? "ntt_pass_kernel<0, true, 0>" : "ntt_pass_kernel<0, false, 0>");
     ProfScope psx(name, bytes);
     const size_t lb = lds_bytes(TB);
 #define P2_LAUNCH(DITV, INVV)                                                                                \

@@ -7,7 +7,7 @@ Units / corrections follow /opt/skills/guides (MI355X_MICROARCH.md "HBM"): the c
 KiB (bytes = value * 1024) and on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide
 coalesced stream, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is taken as reported.
 FETCH_SIZE and WRITE_SIZE come from SEPARATE --pmc passes (TCC slot limit).
-Usage: python profiles/summarize.py r01 [gpurun_out]
+Usage: bash scratch/prof.sh r01b (on the GPU box, via gpurun); python profiles/summarize.py r01b
 """
 import csv
 import glob
@@ -38,13 +38,13 @@ def counter_avgs(d, counter):
 
 def main():
     tag = sys.argv[1]
-    src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
+    src = sys.argv[2] if len(sys.argv) > 2 else os.path.join("gpurun_out", "prof_" + tag)
     here = os.path.dirname(os.path.abspath(__file__))
-    stats = glob.glob(os.path.join(src, "prof_stats", "**", "*_kernel_stats.csv"), recursive=True)
+    stats = glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], os.path.join(here, f"{tag}_kernel_stats.csv"))
-    fetch = counter_avgs(os.path.join(src, "prof_fetch"), "FETCH_SIZE")
-    write = counter_avgs(os.path.join(src, "prof_write"), "WRITE_SIZE")
+    fetch = counter_avgs(os.path.join(src, "fetch"), "FETCH_SIZE")
+    write = counter_avgs(os.path.join(src, "write"), "WRITE_SIZE")
     out = {}
     for k in sorted(set(fetch) | set(write)):
         f, nf = fetch.get(k, (0.0, 0))
@@ -59,7 +59,7 @@ def main():
         }
     with open(os.path.join(here, f"{tag}_pmc_summary.json"), "w") as fo:
         json.dump({"note": "bytes = KiB * 1024; read side doubled (gfx950 FETCH_SIZE correction); separate --pmc passes",
-                   "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline", "kernels": out}, fo, indent=1)
+                   "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline (scratch/prof.sh)", "kernels": out}, fo, indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
         print(f"{k:32s} n={v['launches']:4d} read {v['hbm_read_bytes_per_launch']/1e6:10.1f} MB  write {v['hbm_write_bytes_per_launch']/1e6:10.1f} MB")
 

@@ -94,7 +94,7 @@ struct QuotArgs {
   const gl_t *apow;      // [K][nterms] alpha powers
   const GateDesc *gates; // device copy
   gl_t *out;             // [K][cosets][n]
-  uint32_t tw_shift, d, rate_bits, W, R, NC, num_selectors, K, QF, nchunks, PP, num_gates, nterms;
+  uint32_t tw_shift, d, rate_bits, W, R, NC, num_selectors, K, QF, nchunks, PP, num_gates, nterms, has_poseidon;
   gl_t betas[MAX_CHALLENGES], gammas[MAX_CHALLENGES];
   gl_t pi_hash[4];
   const gl_t *qconst;   // device [3][8]: coset shift 7 w_N^r | Z_H = 7^n w_8^r - 1 | 1 / Z_H
@@ -102,6 +102,8 @@ struct QuotArgs {
   gl_t n_inv;           // 1/n
 };
 void quotient_eval(hipStream_t st, const QuotArgs &a);
+// upload the Poseidon round constants used by PoseidonGate evaluation; 0 = ok
+int poseidon_upload_constants();
 // cross-coset inverse butterflies.  in [K][C][n]: per-coset inverse transforms of
 // the quotient values (bit-reversed coefficient storage, C = 2^rate_bits);
 // inv_scale [C][n] = (1/s_r)^(bitrev p); out [K*C][n]: chunk polynomials

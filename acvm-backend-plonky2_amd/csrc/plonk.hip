@@ -20,8 +20,17 @@
 // constraint vector is ever materialised.  Z(g x) is row k+1 of the same coset
 // (i + 8 = 8(k+1) + r): no halo.  Integer-ALU bound (modmuls), not MFMA.
 #include "internal.hpp"
+#include "poseidon.hpp"
 
 namespace p2 {
+
+// Poseidon round constants for PoseidonGate rows (scalar loads: the index is wave-uniform)
+__constant__ gl_t c_poseidon_rc[360];
+int poseidon_upload_constants() {
+  gl_t rc[360];
+  poseidon_round_constants_host(rc);
+  return hipMemcpyToSymbol(HIP_SYMBOL(c_poseidon_rc), rc, sizeof rc) == hipSuccess ? 0 : -1;
+}
 
 // ------------------------------------------------------------------------------
 // x = w_n^i from the half table tw[j << shift] = w_n^j, j < n/2
@@ -188,7 +197,9 @@ __device__ __forceinline__ gl_t ra_fold(WF &W, uint32_t item0, const gl_t *bv) {
 }
 
 // W(c): wire column c of this row; LC(i): local constant i
-template <class WF, class CF>
+// POSEIDON: compile the PoseidonGate case in (it costs ~170 VGPRs; circuits without public
+// inputs have no PoseidonGate and use the lean instantiation)
+template <bool POSEIDON, class WF, class CF>
 __device__ __forceinline__ void eval_gate(const GateDesc &g, WF W, CF LC, const gl_t *pih, Consumer &out) {
   switch (g.kind) {
   case G_NOOP:
@@ -363,12 +374,59 @@ __device__ __forceinline__ void eval_gate(const GateDesc &g, WF W, CF LC, const 
     out.emit(gl_sub(W(2), W(msb + cb)));
     break;
   }
+  case G_POSEIDON:
+    if constexpr (POSEIDON) {
+    // plonky2 gates/poseidon.rs.  Partial rounds in plain form: the S-box inputs (the only
+    // non-linear points) equal those of upstream's fast factorisation, so all 123 constraint
+    // values coincide.  Wires: in 0..11, out 12..23, swap 24, delta 25..28, full-0 S-box
+    // inputs 29.. (rounds 1-3), partial 65.., full-1 87..
+    gl_t st[12];
+    const gl_t swap = W(24);
+    out.emit(gl_mul(swap, gl_sub(swap, 1)));
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const gl_t l = W(i), r = W(i + 4), dl = W(25 + i);
+      out.emit(gl_sub(gl_mul(swap, gl_sub(r, l)), dl));
+      st[i] = gl_add(l, dl);
+      st[i + 4] = gl_sub(r, dl);
+    }
+#pragma unroll
+    for (int i = 8; i < 12; i++) st[i] = W(i);
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) {
+#pragma unroll
+      for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], c_poseidon_rc[12 * r + i]);
+      const bool full = r < 4 || r >= 26;
+      if (full) {
+        if (r != 0) {
+          const uint32_t base = r < 4 ? 29 + 12 * (r - 1) : 87 + 12 * (r - 26);
+#pragma unroll
+          for (int i = 0; i < 12; i++) {
+            const gl_t sb = W(base + i);
+            out.emit(gl_sub(st[i], sb));
+            st[i] = sb;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = poseidon_sbox(st[i]);
+      } else {
+        const gl_t sb = W(65 + (r - 4));
+        out.emit(gl_sub(st[0], sb));
+        st[0] = poseidon_sbox(sb);
+      }
+      poseidon_mds(st);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) out.emit(gl_sub(st[i], W(12 + i)));
+    }
+    break;
   default:
     break;
   }
 }
 
 // grid: x = k blocks, y = coset
+template <bool POSEIDON>
 __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
   const uint32_t n = 1u << a.d;
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -433,7 +491,7 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
     out.acc0 = 0;
     out.acc1 = 0;
     out.t = t_gates;
-    eval_gate(g, W, LC, a.pi_hash, out);
+    eval_gate<POSEIDON>(g, W, LC, a.pi_hash, out);
     tot0 = gl_add(tot0, gl_mul(f, out.acc0));
     tot1 = gl_add(tot1, gl_mul(f, out.acc1));
   }
@@ -445,8 +503,11 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
 void quotient_eval(hipStream_t st, const QuotArgs &a) {
   const uint32_t n = 1u << a.d;
   const uint32_t threads = n >= 256 ? 256 : 64;
-  ProfScope ps("quotient_kernel", 8.0 * (double)n * (1u << a.rate_bits) * (a.NC + a.R + a.W + a.K * (1 + a.PP) + 2.0 * a.K));
-  hipLaunchKernelGGL(quotient_kernel, dim3((n + threads - 1) / threads, 1u << a.rate_bits), dim3(threads), 0, st, a);
+  ProfScope ps(a.has_poseidon ? "quotient_kernel<true>" : "quotient_kernel<false>", 8.0 * (double)n * (1u << a.rate_bits) * (a.NC + a.R + a.W + a.K * (1 + a.PP) + 2.0 * a.K));
+  if (a.has_poseidon)
+    hipLaunchKernelGGL(quotient_kernel<true>, dim3((n + threads - 1) / threads, 1u << a.rate_bits), dim3(threads), 0, st, a);
+  else
+    hipLaunchKernelGGL(quotient_kernel<false>, dim3((n + threads - 1) / threads, 1u << a.rate_bits), dim3(threads), 0, st, a);
 }
 
 // in [K][C][n]: coefficients (bit-reversed storage) of the per-coset interpolants

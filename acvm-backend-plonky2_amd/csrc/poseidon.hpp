@@ -1,0 +1,107 @@
+// poseidon.hpp -- Poseidon-Goldilocks (width 12, 8 full + 22 partial rounds, x^7): the
+// InnerHasher of KeccakGoldilocksConfig, used on the prove path only for
+// `public_inputs_hash` (host) and inside PoseidonGate constraint evaluation (device).
+// plonky2 0.2.2 hash/poseidon.rs, hash/poseidon_goldilocks.rs, hash/hashing.rs
+// hash_n_to_m_no_pad (un-vendored; reference anchor: plonky2-backend/src/lib.rs:13).
+//
+// The 360 round constants are regenerated the way upstream made them -- `F::rand()` draws
+// from `ChaCha8Rng::seed_from_u64(0)` (PCG32 seed expansion, gen_range widening-multiply
+// sampling) -- and are pinned by plonky2's permutation test vectors in the test-suite.
+#pragma once
+#include "gl.hpp"
+#include <cstring>
+
+namespace p2 {
+
+constexpr uint32_t POSEIDON_MDS_CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+constexpr uint32_t POSEIDON_MDS_DIAG0 = 8;
+
+inline void poseidon_round_constants_host(gl_t out[360]) {
+  auto rol = [](uint32_t x, int n) { return (x << n) | (x >> (32 - n)); };
+  uint64_t state = 0;
+  uint32_t key[8];
+  for (int i = 0; i < 8; i++) {
+    state = state * 6364136223846793005ULL + 11634580027462260723ULL;
+    uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+    key[i] = (xs >> rot) | (xs << ((32 - rot) & 31));
+  }
+  uint32_t blk[16];
+  auto block = [&](uint64_t ctr) {
+    uint32_t s[16] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574};
+    for (int i = 0; i < 8; i++) s[4 + i] = key[i];
+    s[12] = (uint32_t)ctr;
+    s[13] = (uint32_t)(ctr >> 32);
+    s[14] = s[15] = 0;
+    uint32_t w[16];
+    memcpy(w, s, sizeof w);
+    auto qr = [&](int a, int b, int c, int d) {
+      w[a] += w[b]; w[d] = rol(w[d] ^ w[a], 16);
+      w[c] += w[d]; w[b] = rol(w[b] ^ w[c], 12);
+      w[a] += w[b]; w[d] = rol(w[d] ^ w[a], 8);
+      w[c] += w[d]; w[b] = rol(w[b] ^ w[c], 7);
+    };
+    for (int r = 0; r < 4; r++) {
+      qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+      qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; i++) blk[i] = w[i] + s[i];
+  };
+  uint64_t ctr = 0;
+  int pos = 16, got = 0;
+  while (got < 360) {
+    if (pos == 16) { block(ctr++); pos = 0; }
+    uint32_t lo32 = blk[pos++];
+    if (pos == 16) { block(ctr++); pos = 0; }
+    uint32_t hi32 = blk[pos++];
+    unsigned __int128 prod = (unsigned __int128)((uint64_t)lo32 | ((uint64_t)hi32 << 32)) * GL_P;
+    if ((uint64_t)prod <= GL_P - 1) out[got++] = (uint64_t)(prod >> 64);
+  }
+}
+
+// one round's linear layer: out[r] = sum_i st[(i + r) % 12] * CIRC[i] + st[r] * DIAG[r]
+P2_HD void poseidon_mds(gl_t st[12]) {
+  gl_t r[12];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int row = 0; row < 12; row++) {
+    unsigned __int128 acc = 0;  // 13 terms < 2^70 each
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 12; i++) acc += (unsigned __int128)st[(i + row) % 12] * POSEIDON_MDS_CIRC[i];
+    if (row == 0) acc += (unsigned __int128)st[0] * POSEIDON_MDS_DIAG0;
+    r[row] = gl_reduce128((uint64_t)acc, (uint64_t)(acc >> 64));
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int i = 0; i < 12; i++) st[i] = r[i];
+}
+P2_HD gl_t poseidon_sbox(gl_t x) {
+  gl_t x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x2, x);
+  return gl_mul(x4, x3);
+}
+
+inline void poseidon_permute_host(gl_t st[12], const gl_t rc[360]) {
+  for (int r = 0; r < 30; r++) {
+    for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], rc[12 * r + i]);
+    if (r < 4 || r >= 26)
+      for (int i = 0; i < 12; i++) st[i] = poseidon_sbox(st[i]);
+    else
+      st[0] = poseidon_sbox(st[0]);
+    poseidon_mds(st);
+  }
+}
+// hash_n_to_m_no_pad (overwrite-mode sponge, rate 8), 4 outputs; [] -> 0^4 without permuting
+inline void poseidon_hash_no_pad_host(const gl_t *in, size_t n, gl_t out[4], const gl_t rc[360]) {
+  gl_t st[12] = {0};
+  for (size_t off = 0; off < n; off += 8) {
+    size_t k = n - off < 8 ? n - off : 8;
+    for (size_t i = 0; i < k; i++) st[i] = in[off + i];
+    poseidon_permute_host(st, rc);
+  }
+  for (int i = 0; i < 4; i++) out[i] = st[i];
+}
+
+}  // namespace p2

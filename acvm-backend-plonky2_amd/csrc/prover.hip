@@ -10,6 +10,7 @@
 // The product path never touches oracle/; without a HIP device every entry
 // point fails with P2GPU_E_DEVICE.
 #include "internal.hpp"
+#include "poseidon.hpp"
 #include "../../include/p2gpu.h"
 #include <algorithm>
 #include <chrono>
@@ -179,6 +180,7 @@ struct p2gpu_circuit {
   // oracles
   Batch cs, wires, zp, quot;
   dig_t circuit_digest;
+  gl_t poseidon_rc[360];
   // work buffers
   DBuf<gl_t> wires_vals, zp_vals, cp, rowprod, scan_tmp, apow, qvals, qtmp, pw, partial, ext_apow, f01, f01v, fv;
   std::vector<DBuf<gl_t>> fri_coef, fri_vals;
@@ -342,10 +344,15 @@ void path_positions(const Batch &b, uint32_t C, unsigned lgC, size_t m0, unsigne
 
 int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
                size_t *proof_len, p2gpu_timings *tm, double h2d_ms) {
-  if (n_pi != c->num_pi || n_pi != 0) {
-    set_err("public inputs are not supported yet (needs PoseidonGate); got n_pi=%u, circuit has %u", n_pi, c->num_pi);
+  if (n_pi != c->num_pi || (n_pi && !pis)) {
+    set_err("expected %u public inputs, got %u", c->num_pi, n_pi);
     return P2GPU_E_ARG;
   }
+  for (uint32_t i = 0; i < n_pi; i++)
+    if (pis[i] >= GL_P) {
+      set_err("public input %u is not a canonical field element", i);
+      return P2GPU_E_ARG;
+    }
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = c->stream;
   const uint32_t d = c->d, K = c->K, R = c->R, W = c->W, NC = c->NC, QF = c->QF, PP = c->PP, C = c->C;
@@ -362,7 +369,8 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   memset(&T, 0, sizeof T);
   T.h2d_ms = h2d_ms;
 
-  gl_t pih[4] = {0, 0, 0, 0};  // InnerHasher(Poseidon).hash_no_pad([]) = 0^4
+  gl_t pih[4];  // public_inputs_hash = InnerHasher(Poseidon).hash_no_pad(public_inputs); [] -> 0^4
+  poseidon_hash_no_pad_host(pis, n_pi, pih, c->poseidon_rc);
 
   // ---- 1. wires commitment ----
   TRACE(c, "enter");
@@ -425,6 +433,9 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     q.tw_shift = 0; q.d = d; q.rate_bits = c->rate_bits; q.W = W; q.R = R; q.NC = NC;
     q.num_selectors = c->num_selectors; q.K = K; q.QF = QF; q.nchunks = c->nchunks; q.PP = PP;
     q.num_gates = c->num_gates; q.nterms = nterms;
+    q.has_poseidon = 0;
+    for (auto &g : c->gates)
+      if (g.kind == G_POSEIDON) q.has_poseidon = 1;
     for (uint32_t k = 0; k < 2; k++) { q.betas[k] = betas[k]; q.gammas[k] = gammas[k]; }
     for (int i = 0; i < 4; i++) q.pi_hash[i] = pih[i];
     gl_t wN = gl_root(d + c->rate_bits), wC = gl_root(c->rate_bits), gn = gl_pow(GL_GEN, n);
@@ -755,6 +766,7 @@ uint32_t gate_num_constraints(uint32_t kind, const uint32_t p[4]) {
   case G_ARITHMETIC: return p[0];
   case G_BASE_SUM: return 1 + p[1];
   case G_RANDOM_ACCESS: return p[1] * (p[0] + 2) + p[2];
+  case G_POSEIDON: return 123;
   case G_U32_ARITHMETIC: return p[0] * 36;
   case G_U32_ADD_MANY: return p[1] * 21;
   case G_U32_SUBTRACTION: return p[0] * 19;
@@ -867,7 +879,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     memcpy(G.p, &g[1], 16);
     G.sel_index = g[5]; G.group_start = g[6]; G.group_end = g[7]; G.num_constraints = g[8]; G.degree = g[9];
     G.num_constants = g[10]; G.pad = 0;
-    if (G.kind >= G_KIND_COUNT || G.kind == G_POSEIDON) return fail(P2GPU_E_BLOB, "unsupported gate kind in blob");
+    if (G.kind >= G_KIND_COUNT) return fail(P2GPU_E_BLOB, "unsupported gate kind in blob");
     if (G.num_constraints != gate_num_constraints(G.kind, G.p)) return fail(P2GPU_E_BLOB, "gate constraint count mismatch");
     if (G.kind == G_RANDOM_ACCESS && G.p[0] > 6) return fail(P2GPU_E_BLOB, "RandomAccessGate bits > 6 unsupported");
     if (G.sel_index >= c->num_selectors || G.group_end > c->num_gates) return fail(P2GPU_E_BLOB, "bad selector info");
@@ -905,6 +917,8 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     return P2GPU_E_DEVICE;                            \
   }
   CK(hipSetDevice(c->device), "hipSetDevice");
+  poseidon_round_constants_host(c->poseidon_rc);
+  if (poseidon_upload_constants()) return fail(P2GPU_E_DEVICE, "uploading Poseidon constants failed");
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
   hipStream_t st = c->stream;
   const uint32_t d = c->d, K = c->K, C = c->C;

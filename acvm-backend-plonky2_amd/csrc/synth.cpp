@@ -15,6 +15,7 @@
 // arithmetic_u32.rs:376-426, add_many_u32.rs:329-378, subtraction_u32.rs:298-343,
 // range_check_u32.rs:198-220, comparison.rs:439-537.
 #include "gl.hpp"
+#include "poseidon.hpp"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -264,8 +265,10 @@ extern "C" {
 
 // mix: "arith" | "sha" | "ecdsa".  Returns 0 ok.  Outputs are malloc'ed; free
 // with p2synth_free.  wires_out is [num_wires][2^d] column-major.
-int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint8_t **blob_out, size_t *blob_len,
-                 uint64_t **wires_out, uint32_t *num_wires_out) {
+// num_pi > 0 adds what `build()` adds for public inputs: PoseidonGate rows hashing them (overwrite-mode
+// sponge, 8 per permutation) and the PublicInputGate row wired to the hash; pis_out receives the values.
+int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint32_t num_pi, uint8_t **blob_out, size_t *blob_len,
+                 uint64_t **wires_out, uint32_t *num_wires_out, uint64_t *pis_out) {
   const uint32_t W = 234, R = 80, K = 2, QF = 8, RATE_BITS = 3, CAP_H = 4, POW_BITS = 16, QUERIES = 28;
   if (d < 5 || d > 24) return -1;
   size_t n = (size_t)1 << d;
@@ -294,6 +297,11 @@ int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint8_t **blob_out,
   } else {
     return -2;
   }
+  const uint32_t nperm = (num_pi + 7) / 8;
+  if (num_pi > 64 || (size_t)nperm + 8 > n) return -4;
+  if (num_pi)
+    gates.push_back(mk(G_POSEIDON, 0, 0, 0,
+                       "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>", 7, 123, 0, 0));
   // circuit_builder.rs build(): gates sorted by (degree, id)
   std::sort(gates.begin(), gates.end(), [](const GateDef &a, const GateDef &b) {
     return a.degree != b.degree ? a.degree < b.degree : a.id < b.id;
@@ -347,6 +355,7 @@ int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint8_t **blob_out,
     for (size_t r = 0; r < n; r++) {
       if (r == 0) row_gate[r] = gate_index(G_PUBLIC_INPUT, 0);
       else if (r == 1) row_gate[r] = gate_index(G_CONSTANT, 0);
+      else if (r < 2 + nperm) row_gate[r] = gate_index(G_POSEIDON, 0);
       else if (r >= n - pad) row_gate[r] = gi_noop;
       else {
         double u = (double)(b.rng.next() >> 11) / 9007199254740992.0 * acc;
@@ -356,23 +365,76 @@ int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint8_t **blob_out,
       }
     }
   }
-  // fill rows (row 1 first so the constants 0/1 exist before the PI row connects to them)
+  // fill rows (row 1 first so the constants 0/1 exist before other rows connect to them)
   gl_t lc[8];
+  gl_t pi_hash[4] = {0, 0, 0, 0};
+  std::vector<gl_t> pis(num_pi);
   std::vector<size_t> order;
   order.push_back(1);
+  for (size_t r = 2; r < 2 + (size_t)nperm; r++) order.push_back(r);
   order.push_back(0);
-  for (size_t r = 2; r < n; r++) order.push_back(r);
+  for (size_t r = 2 + nperm; r < n; r++) order.push_back(r);
+  gl_t prc[360];
+  if (num_pi) poseidon_round_constants_host(prc);
   for (size_t r : order) {
     const GateDef &g = gates[row_gate[r]];
     memset(lc, 0, sizeof lc);
-    fill_row(b, g, (uint32_t)r, lc);
+    if (g.kind == G_POSEIDON) {
+      // in-circuit hash_n_to_hash_no_pad (hash/hashing.rs): PoseidonGate row = one permutation, swap = 0
+      const uint32_t c = (uint32_t)r - 2, row = (uint32_t)r;
+      gl_t st[12];
+      for (uint32_t i = 0; i < 12; i++) {
+        uint32_t k = 8 * c + i;
+        if (i < 8 && k < num_pi) {
+          pis[k] = b.rng.field();
+          b.out_f(row, i, pis[k]);  // the public-input target; later gates may copy from it
+          st[i] = pis[k];
+        } else if (c == 0) {
+          b.w(row, i) = 0;
+          b.connect(Cell{row, i}, Cell{1, 0});
+          st[i] = 0;
+        } else {
+          st[i] = b.w(row - 1, 12 + i);
+          b.w(row, i) = st[i];
+          b.connect(Cell{row, i}, Cell{row - 1, 12 + i});
+        }
+      }
+      b.w(row, 24) = 0;  // swap
+      b.connect(Cell{row, 24}, Cell{1, 0});
+      for (uint32_t i = 0; i < 4; i++) b.w(row, 25 + i) = 0;  // deltas
+      for (int rd = 0; rd < 30; rd++) {
+        for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], prc[12 * rd + i]);
+        if (rd < 4 || rd >= 26) {
+          if (rd != 0) {
+            uint32_t base = rd < 4 ? 29 + 12 * (rd - 1) : 87 + 12 * (rd - 26);
+            for (int i = 0; i < 12; i++) b.w(row, base + i) = st[i];
+          }
+          for (int i = 0; i < 12; i++) st[i] = poseidon_sbox(st[i]);
+        } else {
+          b.w(row, 65 + (rd - 4)) = st[0];
+          st[0] = poseidon_sbox(st[0]);
+        }
+        poseidon_mds(st);
+      }
+      for (uint32_t i = 0; i < 12; i++) b.out_f(row, 12 + i, st[i]);
+      if (c == nperm - 1)
+        for (int i = 0; i < 4; i++) pi_hash[i] = st[i];
+    } else if (g.kind == G_PUBLIC_INPUT) {
+      for (uint32_t i = 0; i < 4; i++) {
+        b.w((uint32_t)r, i) = pi_hash[i];
+        if (num_pi) b.connect(Cell{(uint32_t)r, i}, Cell{1 + nperm, 12 + i});
+        else b.connect(Cell{(uint32_t)r, i}, Cell{1, 0});  // hash of no public inputs = constant zero
+      }
+    } else {
+      fill_row(b, g, (uint32_t)r, lc);
+    }
     uint32_t gi = row_gate[r];
     for (uint32_t s = 0; s < num_selectors; s++)
       constants[(size_t)s * n + r] = (num_selectors == 1 || s == gsel[gi]) ? gi : 0xFFFFFFFFull;
     for (uint32_t k = 0; k < g.nconst; k++) constants[(size_t)(num_selectors + k) * n + r] = lc[k];
-    if (r == 0)
-      for (uint32_t i = 0; i < 4; i++) b.connect(Cell{0, i}, Cell{1, 0});  // pi_hash parts = constant zero
   }
+  if (pis_out)
+    for (uint32_t i = 0; i < num_pi; i++) pis_out[i] = pis[i];
 
   // plonk/permutation_argument.rs: sigma maps each routed cell to the next cell of its partition class
   std::vector<gl_t> k_is(R);
@@ -419,7 +481,7 @@ int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint8_t **blob_out,
   h[0] = 0x43473250u; h[1] = 1; h[2] = d; h[3] = W; h[4] = R; h[5] = NC; h[6] = num_selectors; h[7] = K; h[8] = QF;
   h[9] = RATE_BITS; h[10] = CAP_H; h[11] = POW_BITS; h[12] = QUERIES; h[13] = (uint32_t)arity.size();
   for (size_t i = 0; i < arity.size(); i++) h[14 + i] = arity[i];
-  h[22] = 0; h[23] = ng; h[24] = 0; h[25] = 0; h[26] = (R + QF - 1) / QF - 1;
+  h[22] = 0; h[23] = ng; h[24] = num_pi; h[25] = 0; h[26] = (R + QF - 1) / QF - 1;
   memcpy(blob, h, sizeof h);
   size_t off = sizeof h;
   for (uint32_t i = 0; i < ng; i++) {

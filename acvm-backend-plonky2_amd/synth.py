@@ -28,15 +28,18 @@ def _lib():
     return _LIB
 
 
-def make_circuit(degree_bits, mix="arith", seed=1):
-    """Returns (blob: np.uint8[...], wires: np.uint64[num_wires][2^degree_bits])."""
+def make_circuit(degree_bits, mix="arith", seed=1, num_public_inputs=0):
+    """Returns (blob: np.uint8[...], wires: np.uint64[num_wires][2^degree_bits]) and, when
+    num_public_inputs > 0, additionally the public input values (np.uint64[num_public_inputs])."""
     lib = _lib()
     blob = ctypes.POINTER(ctypes.c_uint8)()
     blen = ctypes.c_size_t()
     wires = ctypes.POINTER(ctypes.c_uint64)()
     nw = ctypes.c_uint32()
-    rc = lib.p2synth_make(ctypes.c_uint(degree_bits), mix.encode(), ctypes.c_uint64(seed), ctypes.byref(blob),
-                          ctypes.byref(blen), ctypes.byref(wires), ctypes.byref(nw))
+    pis = np.zeros(max(num_public_inputs, 1), dtype=np.uint64)
+    rc = lib.p2synth_make(ctypes.c_uint(degree_bits), mix.encode(), ctypes.c_uint64(seed),
+                          ctypes.c_uint32(num_public_inputs), ctypes.byref(blob), ctypes.byref(blen),
+                          ctypes.byref(wires), ctypes.byref(nw), ctypes.c_void_p(pis.ctypes.data))
     if rc != 0:
         raise ValueError(f"p2synth_make({degree_bits}, {mix!r}) failed: {rc}")
     try:
@@ -45,4 +48,6 @@ def make_circuit(degree_bits, mix="arith", seed=1):
     finally:
         lib.p2synth_free(blob)
         lib.p2synth_free(wires)
+    if num_public_inputs:
+        return b, w, pis[:num_public_inputs].copy()
     return b, w

@@ -50,7 +50,7 @@
  * Gate kinds (closed registry, plonky2-backend/src/actions/write_vk_action.rs:35-62):
  *   0 Noop  1 Constant{p0=num_consts}  2 PublicInput  3 Arithmetic{p0=num_ops}
  *   4 BaseSum{p0=B,p1=num_limbs}  5 RandomAccess{p0=bits,p1=copies,p2=extra_consts}
- *   6 Poseidon (rejected for now)  7 U32Arithmetic{p0=num_ops}
+ *   6 Poseidon (PoseidonGate, width 12)  7 U32Arithmetic{p0=num_ops}
  *   8 U32AddMany{p0=num_addends,p1=num_ops}  9 U32Subtraction{p0=num_ops}
  *   10 U32RangeCheck{p0=num_input_limbs}  11 Comparison{p0=num_bits,p1=num_chunks}
  *

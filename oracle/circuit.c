@@ -58,6 +58,7 @@ uint32_t gate_num_constraints(uint32_t kind, const uint32_t p[4]) {
   case G_ARITHMETIC: return p[0];
   case G_BASE_SUM: return 1 + p[1];
   case G_RANDOM_ACCESS: return p[1] * (p[0] + 2) + p[2];
+  case G_POSEIDON: return 123;
   case G_U32_ARITHMETIC: return p[0] * (4 + 32);          /* arithmetic_u32.rs:281-283 */
   case G_U32_ADD_MANY: return p[1] * (3 + 18);            /* add_many_u32.rs:282-284 */
   case G_U32_SUBTRACTION: return p[0] * (3 + 16);         /* subtraction_u32.rs:226-228 */
@@ -74,6 +75,7 @@ uint32_t gate_degree(uint32_t kind, const uint32_t p[4]) {
   case G_ARITHMETIC: return 3;
   case G_BASE_SUM: return p[0];
   case G_RANDOM_ACCESS: return p[0] + 1;
+  case G_POSEIDON: return 7;
   case G_U32_ARITHMETIC: return 4;
   case G_U32_ADD_MANY: return 4;
   case G_U32_SUBTRACTION: return 4;
@@ -98,6 +100,7 @@ uint32_t gate_num_wires(uint32_t kind, const uint32_t p[4]) {
   case G_ARITHMETIC: return 4 * p[0];
   case G_BASE_SUM: return 1 + p[1];
   case G_RANDOM_ACCESS: return (2 + (1u << p[0])) * p[1] + p[2] + p[0] * p[1];
+  case G_POSEIDON: return 135;
   case G_U32_ARITHMETIC: return p[0] * 38;
   case G_U32_ADD_MANY: return p[1] * (p[0] + 3 + 18);
   case G_U32_SUBTRACTION: return p[0] * 21;
@@ -153,7 +156,7 @@ int circuit_parse(circuit_t *c, const uint8_t *blob, size_t len) {
     G->num_constraints = g[8];
     G->degree = g[9];
     G->num_constants = g[10];
-    if (G->kind >= G_KIND_COUNT || G->kind == G_POSEIDON) return -4;
+    if (G->kind >= G_KIND_COUNT) return -4;
     if (G->num_constraints != gate_num_constraints(G->kind, G->p)) return -5;
     if (G->num_constraints > c->num_gate_constraints) c->num_gate_constraints = G->num_constraints;
   }

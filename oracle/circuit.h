@@ -15,7 +15,7 @@
  *     comparison.rs:337-414       ComparisonGate
  *   stock plonky2 0.2.2 gates (absent):
  *     NoopGate, ConstantGate, PublicInputGate, ArithmeticGate, BaseSumGate<B>,
- *     RandomAccessGate
+ *     RandomAccessGate, PoseidonGate
  * The closed set of gate kinds is the registry at
  * plonky2-backend/src/actions/write_vk_action.rs:35-62.
  */
@@ -32,7 +32,7 @@ enum {
   G_ARITHMETIC = 3,    /* p0 = num_ops */
   G_BASE_SUM = 4,      /* p0 = base B, p1 = num_limbs */
   G_RANDOM_ACCESS = 5, /* p0 = bits, p1 = num_copies, p2 = num_extra_constants */
-  G_POSEIDON = 6,      /* not yet supported */
+  G_POSEIDON = 6,      /* PoseidonGate (width 12); no parameters */
   G_U32_ARITHMETIC = 7,  /* p0 = num_ops */
   G_U32_ADD_MANY = 8,    /* p0 = num_addends, p1 = num_ops */
   G_U32_SUBTRACTION = 9, /* p0 = num_ops */

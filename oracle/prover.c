@@ -44,6 +44,7 @@ int orc_circuit_create(const uint8_t *blob, size_t len, orc_circuit **out) {
   orc_circuit *oc = (orc_circuit *)calloc(1, sizeof *oc);
   oc->blob = (uint8_t *)malloc(len);
   memcpy(oc->blob, blob, len);
+  poseidon_init(); /* not thread-safe: force it before any OpenMP region */
   int rc = circuit_load(&oc->c, oc->blob, len);
   if (rc) {
     circuit_free(&oc->c);
@@ -60,6 +61,7 @@ int orc_circuit_create_verifier(const uint8_t *blob, size_t len, const uint8_t *
   /* only the header, gate table and k_is are needed: keep a private copy of the whole blob */
   oc->blob = (uint8_t *)malloc(len);
   memcpy(oc->blob, blob, len);
+  poseidon_init();
   int rc = circuit_load_verifier(&oc->c, oc->blob, len, cap, digest);
   if (rc) {
     circuit_free(&oc->c);

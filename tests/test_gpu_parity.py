@@ -92,6 +92,21 @@ def test_proof_bytes_match_oracle(pkg, orc, gpu, d, mix, seed):
     cd.close()
 
 
+@pytest.mark.parametrize("d,mix,npi", [(6, "arith", 1), (8, "sha", 4), (9, "ecdsa", 9), (12, "ecdsa", 20)])
+def test_public_inputs_proof_bytes_match_oracle(pkg, orc, gpu, d, mix, npi):
+    """PoseidonGate rows + Poseidon public_inputs_hash (InnerHasher) on the GPU path."""
+    blob, wires, pis = pkg.make_circuit(d, mix, 17, num_public_inputs=npi)
+    cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
+    assert cd.constants_sigmas_cap() == oc.cap()
+    expect, _ = oc.prove(wires, public_inputs=pis)
+    got = cd.prove(wires, public_inputs=pis).to_bytes()
+    assert got == expect and oc.verify(got)
+    assert got[-8 * npi:] == pis.tobytes()
+    with pytest.raises(pkg.P2GpuError):
+        cd.prove(wires)  # public inputs missing
+    cd.close()
+
+
 def test_golden_proof_digests_on_gpu(pkg, gpu):
     """Committed regression vectors (tests/golden/proof_digests.json) without running the oracle."""
     with open(os.path.join(GOLDEN, "proof_digests.json")) as f:

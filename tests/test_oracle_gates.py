@@ -148,7 +148,35 @@ def test_stock_gates(orc):
     assert orc.gate_eval(G_RANDOM_ACCESS, [4, 4, 2], _pad(w), consts=[e0, e1]).any()
 
 
+def test_poseidon_gate_constraint(pkg, orc):
+    """PoseidonGate (gates/poseidon.rs, 135 wires, 123 constraints, degree 7): the rows the
+    generator emits for public-input hashing satisfy it; breaking an S-box wire does not."""
+    blob, wires, pis = pkg.make_circuit(6, "arith", 5, num_public_inputs=9)
+    for row in (2, 3):  # two permutations for 9 inputs (rate 8)
+        w = wires[:, row].copy()
+        out = orc.gate_eval(6, [], w)
+        assert len(out) == 123 and not out.any()
+        # the outputs are the Poseidon permutation of the inputs
+        st = w[:12].copy()
+        orc.lib().orc_poseidon_permute(st.ctypes.data)
+        assert np.array_equal(st, w[12:24])
+        bad = w.copy()
+        bad[65 + 7] = (int(bad[65 + 7]) + 1) % P  # a partial-round S-box input
+        assert orc.gate_eval(6, [], bad).any()
+    # second permutation: capacity lanes carried over from the first one's outputs
+    assert np.array_equal(wires[8:12, 3], wires[20:24, 2]) and wires[0, 3] == pis[8]
+    # swap = 1 with matching deltas is also accepted by the gate (Merkle-path mode)
+    w = wires[:, 2].copy()
+    w[24] = 1
+    for i in range(4):
+        w[25 + i] = (int(w[i + 4]) - int(w[i])) % P
+    st = np.concatenate([w[4:8], w[0:4], w[8:12]]).copy()
+    out = orc.gate_eval(6, [], w)
+    assert out[:5].tolist() == [0] * 5 and out[5:].any()  # swap/delta constraints hold; the trace was for swap = 0
+
+
 @pytest.mark.parametrize("kind,params", [
+    (6, []),
     (G_ARITHMETIC, [20]), (G_BASE_SUM, [2, 32]), (G_BASE_SUM, [4, 16]), (G_RANDOM_ACCESS, [4, 4, 2]),
     (G_U32_ARITHMETIC, [6]), (G_U32_ADD_MANY, [3, 9]), (G_U32_SUBTRACTION, [11]), (G_U32_RANGE_CHECK, [8]),
     (G_COMPARISON, [32, 16]), (G_CONSTANT, [2]), (G_PUBLIC_INPUT, []),

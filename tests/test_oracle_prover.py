@@ -50,6 +50,28 @@ def test_golden_proof_digests(pkg, orc):
         assert int(tr.pow_witness) == g["pow_witness"]
 
 
+@pytest.mark.parametrize("mix,npi", [("arith", 1), ("sha", 4), ("ecdsa", 8), ("ecdsa", 9), ("arith", 20)])
+def test_public_inputs_poseidon_gate(pkg, orc, mix, npi):
+    """Circuits with public inputs (like the reference's basic_div: `y: pub Field`, sha256_4:
+    `pub [u8; 4]`): build() adds PoseidonGate rows hashing them and wires the hash into the
+    PublicInputGate; the proof ends with the public inputs (no length prefix)."""
+    blob, wires, pis = pkg.make_circuit(7, mix, 11, num_public_inputs=npi)
+    assert int(blob[:256].view(np.uint32)[24]) == npi
+    oc = orc.OracleCircuit(blob)
+    proof, tr = oc.prove(wires, public_inputs=pis)
+    assert oc.verify(proof)
+    assert proof[-8 * npi:] == pis.tobytes()
+    assert any(tr.pi_hash)
+    # a different claimed public input is rejected
+    bad = bytearray(proof)
+    bad[-8] ^= 1
+    assert not oc.verify(bytes(bad))
+    # proving with the wrong public inputs gives a rejected proof
+    wrong = pis.copy()
+    wrong[0] = (int(wrong[0]) + 1) % P
+    assert not oc.verify(oc.prove(wires, public_inputs=wrong)[0])
+
+
 def test_unsatisfied_witness_is_rejected(pkg, orc):
     blob, wires = pkg.make_circuit(7, "ecdsa", 9)
     oc = orc.OracleCircuit(blob)

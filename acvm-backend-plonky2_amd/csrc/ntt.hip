@@ -105,6 +105,9 @@ __device__ __forceinline__ void dft_regs(gl_t (&v)[1 << LOGR]) {
 __device__ __forceinline__ uint32_t pidx(uint32_t e) { return e + (e >> 4); }
 
 constexpr int MAX_ROUNDS = 4;
+#ifndef NTT_TILE_BITS
+#define NTT_TILE_BITS 12
+#endif
 struct PassArgs {
   const gl_t *src;    // [cols][n] (or [cosets][cols][n])
   gl_t *dst;          // [cosets][cols][n]
@@ -197,12 +200,12 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(PassArgs A) {
   const gl_t *scale = A.scale ? A.scale + (size_t)coset * n : nullptr;
   const uint32_t tsize = 1u << TB;
   if constexpr (TBC != 0) {
-    constexpr int PER = (1 << TBC) / 256;
+    constexpr int PER = 16, NT = (1 << TBC) / PER;
     gl_t x[PER];
     uint32_t g[PER];
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-      g[i] = gidx(threadIdx.x + i * 256, hi_base, lo0, A.s, A.tb);
+      g[i] = gidx(threadIdx.x + i * NT, hi_base, lo0, A.s, A.tb);
       x[i] = src[g[i]];
     }
     if (scale) {
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(PassArgs A) {
       for (int i = 0; i < PER; i++) x[i] = gl_mul(x[i], sc[i]);
     }
 #pragma unroll
-    for (int i = 0; i < PER; i++) lds[pidx(threadIdx.x + i * 256)] = x[i];
+    for (int i = 0; i < PER; i++) lds[pidx(threadIdx.x + i * NT)] = x[i];
   } else {
     for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
       const uint32_t g = gidx(e, hi_base, lo0, A.s, A.tb);
@@ -240,16 +243,16 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(PassArgs A) {
   }
   const bool post = A.post != 1;
   if constexpr (TBC != 0) {
-    constexpr int PER = (1 << TBC) / 256;
+    constexpr int PER = 16, NT = (1 << TBC) / PER;
     gl_t x[PER];
 #pragma unroll
-    for (int i = 0; i < PER; i++) x[i] = lds[pidx(threadIdx.x + i * 256)];
+    for (int i = 0; i < PER; i++) x[i] = lds[pidx(threadIdx.x + i * NT)];
     if (post) {
 #pragma unroll
       for (int i = 0; i < PER; i++) x[i] = gl_mul(x[i], A.post);
     }
 #pragma unroll
-    for (int i = 0; i < PER; i++) dst[gidx(threadIdx.x + i * 256, hi_base, lo0, A.s, A.tb)] = x[i];
+    for (int i = 0; i < PER; i++) dst[gidx(threadIdx.x + i * NT, hi_base, lo0, A.s, A.tb)] = x[i];
   } else {
     for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
       gl_t x = lds[pidx(e)];
@@ -290,7 +293,7 @@ NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse) {
   p->d = d;
   p->dit = dit;
   p->inverse = inverse;
-  const uint32_t TBMAX = 12;
+  const uint32_t TBMAX = NTT_TILE_BITS;
   const uint32_t b = d < TBMAX ? d : TBMAX;
   struct P { uint32_t s, a, tb; };
   std::vector<P> strided;
@@ -386,7 +389,7 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     const double bytes = 16.0 * ((double)cols * cosets * ((size_t)1 << d));
     // same spelling as rocprofv3's demangled kernel names, so the bench line and profiles/ agree
     const char *name;
-    if (TB == 12)
+    if (TB == NTT_TILE_BITS)
       name = plan->dit ? (plan->inverse ? "ntt_pass_kernel<1, true, 12>" : "ntt_pass_kernel<1, false, 12>")
                        : (plan->inverse ? "ntt_pass_kernel<0, true, 12>" : "ntt_pass_kernel<0, false, 12>");
     else
@@ -396,7 +399,7 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     const size_t lb = lds_bytes(TB);
 #define P2_LAUNCH(DITV, INVV)                                                                                \
   do {                                                                                                       \
-    if (TB == 12) hipLaunchKernelGGL((ntt_pass_kernel<DITV, INVV, 12>), grid, dim3(256), lb, st, A);          \
+    if (TB == NTT_TILE_BITS) hipLaunchKernelGGL((ntt_pass_kernel<DITV, INVV, NTT_TILE_BITS>), grid, dim3((1u << NTT_TILE_BITS) / 16), lb, st, A);           \
     else hipLaunchKernelGGL((ntt_pass_kernel<DITV, INVV, 0>), grid, dim3(threads), lb, st, A);               \
   } while (0)
     if (plan->dit) {

@@ -834,7 +834,9 @@ size_t p2gpu_proof_size_bound(const p2gpu_circuit *c) {
   size_t sz = 3 * ncap * 25 + 16 * (ncs + c->W + nzp + nq + c->K) + c->n_steps * ncap * 25;
   size_t per_q = 8 * (ncs + c->W + nzp + nq) + 4 * (1 + 25 * (size_t)(c->d + c->rate_bits));
   for (uint32_t s = 0; s < c->n_steps; s++) per_q += (16u << c->arity[s]) + 1 + 25 * (size_t)(c->d + c->rate_bits);
-  sz += per_q * c->num_queries + 16 * c->n + 8 + 8 * c->num_pi + 64;
+  size_t n_final = c->n;
+  for (uint32_t s = 0; s < c->n_steps; s++) n_final >>= c->arity[s];
+  sz += per_q * c->num_queries + 16 * n_final + 8 + 8 * c->num_pi + 64;
   return sz;
 }
 

@@ -4,20 +4,10 @@
 #include <vector>
 #include "gl.hpp"
 #include "keccak.hpp"
+#include "gates.hpp"
 
 namespace p2 {
 
-enum {
-  G_NOOP = 0, G_CONSTANT = 1, G_PUBLIC_INPUT = 2, G_ARITHMETIC = 3, G_BASE_SUM = 4, G_RANDOM_ACCESS = 5,
-  G_POSEIDON = 6, G_U32_ARITHMETIC = 7, G_U32_ADD_MANY = 8, G_U32_SUBTRACTION = 9, G_U32_RANGE_CHECK = 10,
-  G_COMPARISON = 11, G_KIND_COUNT
-};
-
-struct GateDesc {
-  uint32_t kind, p[4];
-  uint32_t sel_index, group_start, group_end;
-  uint32_t num_constraints, degree, num_constants, pad;
-};
 constexpr int MAX_GATES = 32;
 constexpr int MAX_CHALLENGES = 2;
 constexpr int MAX_ROUTED = 128;

@@ -20,7 +20,7 @@
 // constraint vector is ever materialised.  Z(g x) is row k+1 of the same coset
 // (i + 8 = 8(k+1) + r): no halo.  Integer-ALU bound (modmuls), not MFMA.
 #include "internal.hpp"
-#include "poseidon.hpp"
+#include "gates.hpp"
 
 namespace p2 {
 
@@ -173,258 +173,6 @@ struct Consumer {
   }
 };
 
-__device__ __forceinline__ gl_t range_product(gl_t v, uint32_t base) {
-  gl_t p = v;
-  for (uint32_t x = 1; x < base; x++) p = gl_mul(p, gl_sub(v, x));
-  return p;
-}
-__device__ __forceinline__ gl_t range4(gl_t v) {
-  // v (v-1) (v-2) (v-3)
-  gl_t a = gl_mul(v, gl_sub(v, 1));
-  gl_t b = gl_mul(gl_sub(v, 2), gl_sub(v, 3));
-  return gl_mul(a, b);
-}
-
-template <int LVL, class WF>
-__device__ __forceinline__ gl_t ra_fold(WF &W, uint32_t item0, const gl_t *bv) {
-  if constexpr (LVL == 0) {
-    return W(item0);
-  } else {
-    gl_t x = ra_fold<LVL - 1>(W, item0, bv);
-    gl_t y = ra_fold<LVL - 1>(W, item0 + (1u << (LVL - 1)), bv);
-    return gl_add(x, gl_mul(bv[LVL - 1], gl_sub(y, x)));
-  }
-}
-
-// W(c): wire column c of this row; LC(i): local constant i
-// POSEIDON: compile the PoseidonGate case in (it costs ~170 VGPRs; circuits without public
-// inputs have no PoseidonGate and use the lean instantiation)
-template <bool POSEIDON, class WF, class CF>
-__device__ __forceinline__ void eval_gate(const GateDesc &g, WF W, CF LC, const gl_t *pih, Consumer &out) {
-  switch (g.kind) {
-  case G_NOOP:
-    break;
-  case G_CONSTANT:
-    for (uint32_t i = 0; i < g.p[0]; i++) out.emit(gl_sub(LC(i), W(i)));
-    break;
-  case G_PUBLIC_INPUT:
-    for (uint32_t i = 0; i < 4; i++) out.emit(gl_sub(W(i), pih[i]));
-    break;
-  case G_ARITHMETIC: {
-    const gl_t c0 = LC(0), c1 = LC(1);
-#pragma unroll 4
-    for (uint32_t i = 0; i < g.p[0]; i++) {
-      gl_t m0 = W(4 * i), m1 = W(4 * i + 1), ad = W(4 * i + 2), o = W(4 * i + 3);
-      gl_t comp = gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(ad, c1));
-      out.emit(gl_sub(o, comp));
-    }
-    break;
-  }
-  case G_BASE_SUM: {
-    const uint32_t B = g.p[0], L = g.p[1];
-    gl_t acc = 0;
-#pragma unroll 8
-    for (uint32_t i = L; i-- > 0;) acc = gl_add(gl_mul_small(acc, B), W(1 + i));
-    out.emit(gl_sub(acc, W(0)));
-#pragma unroll 8
-    for (uint32_t i = 0; i < L; i++) out.emit(range_product(W(1 + i), B));
-    break;
-  }
-  case G_RANDOM_ACCESS: {
-    const uint32_t bits = g.p[0], copies = g.p[1], extra = g.p[2], vec = 1u << bits;
-    const uint32_t routed = (2 + vec) * copies + extra;
-    for (uint32_t c = 0; c < copies; c++) {
-      const uint32_t base = (2 + vec) * c, bw = routed + c * bits;
-      for (uint32_t b = 0; b < bits; b++) {
-        gl_t bv = W(bw + b);
-        out.emit(gl_mul(bv, gl_sub(bv, 1)));
-      }
-      gl_t rec = 0;
-      for (uint32_t b = bits; b-- > 0;) rec = gl_add(gl_dbl(rec), W(bw + b));
-      out.emit(gl_sub(rec, W(base)));
-      // fold the list: the nested multiplexer x + b (y - x), lowest bit innermost (same
-      // expression tree as folding pairs level by level), evaluated depth-first with
-      // compile-time indices so nothing spills to scratch
-      gl_t bv[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (uint32_t b = 0; b < 6; b++)
-        if (b < bits) bv[b] = W(bw + b);
-      gl_t folded;
-      switch (bits) {
-      case 1: folded = ra_fold<1>(W, base + 2, bv); break;
-      case 2: folded = ra_fold<2>(W, base + 2, bv); break;
-      case 3: folded = ra_fold<3>(W, base + 2, bv); break;
-      case 4: folded = ra_fold<4>(W, base + 2, bv); break;
-      case 5: folded = ra_fold<5>(W, base + 2, bv); break;
-      case 6: folded = ra_fold<6>(W, base + 2, bv); break;
-      default: folded = W(base + 2); break;
-      }
-      out.emit(gl_sub(folded, W(base + 1)));
-    }
-    for (uint32_t i = 0; i < extra; i++) out.emit(gl_sub(LC(i), W((2 + vec) * copies + i)));
-    break;
-  }
-  case G_U32_ARITHMETIC: {
-    const uint32_t ops = g.p[0];
-    for (uint32_t i = 0; i < ops; i++) {
-      gl_t m0 = W(6 * i), m1 = W(6 * i + 1), ad = W(6 * i + 2);
-      gl_t lo = W(6 * i + 3), hi = W(6 * i + 4), inv = W(6 * i + 5);
-      gl_t computed = gl_add(gl_mul(m0, m1), ad);
-      gl_t diff = gl_sub(0xFFFFFFFFULL, hi);
-      gl_t hi_not_max = gl_sub(gl_mul(inv, diff), 1);
-      out.emit(gl_mul(hi_not_max, lo));
-      gl_t combined = gl_add(gl_mul(hi, 1ULL << 32), lo);
-      out.emit(gl_sub(combined, computed));
-      gl_t cl = 0, ch = 0;
-#pragma unroll 8
-      for (uint32_t j = 32; j-- > 0;) {
-        gl_t limb = W(6 * ops + 32 * i + j);
-        out.emit(range4(limb));
-        if (j < 16) cl = gl_add(gl_mul_small(cl, 4), limb);
-        else ch = gl_add(gl_mul_small(ch, 4), limb);
-      }
-      out.emit(gl_sub(cl, lo));
-      out.emit(gl_sub(ch, hi));
-    }
-    break;
-  }
-  case G_U32_ADD_MANY: {
-    const uint32_t na = g.p[0], ops = g.p[1];
-    for (uint32_t i = 0; i < ops; i++) {
-      const uint32_t b = (na + 3) * i;
-      gl_t computed = 0;
-      for (uint32_t j = 0; j <= na; j++) computed = gl_add(computed, W(b + j));
-      gl_t res = W(b + na + 1), oc = W(b + na + 2);
-      gl_t combined = gl_add(gl_mul(oc, 1ULL << 32), res);
-      out.emit(gl_sub(combined, computed));
-      gl_t cr = 0, cc = 0;
-#pragma unroll 6
-      for (uint32_t j = 18; j-- > 0;) {
-        gl_t limb = W((na + 3) * ops + 18 * i + j);
-        out.emit(range4(limb));
-        if (j < 16) cr = gl_add(gl_mul_small(cr, 4), limb);
-        else cc = gl_add(gl_mul_small(cc, 4), limb);
-      }
-      out.emit(gl_sub(cr, res));
-      out.emit(gl_sub(cc, oc));
-    }
-    break;
-  }
-  case G_U32_SUBTRACTION: {
-    const uint32_t ops = g.p[0];
-    for (uint32_t i = 0; i < ops; i++) {
-      gl_t x = W(5 * i), y = W(5 * i + 1), bin = W(5 * i + 2), res = W(5 * i + 3), bout = W(5 * i + 4);
-      gl_t init = gl_sub(gl_sub(x, y), bin);
-      out.emit(gl_sub(res, gl_add(init, gl_mul(bout, 1ULL << 32))));
-      gl_t comb = 0;
-#pragma unroll 8
-      for (uint32_t j = 16; j-- > 0;) {
-        gl_t limb = W(5 * ops + 16 * i + j);
-        out.emit(range4(limb));
-        comb = gl_add(gl_mul_small(comb, 4), limb);
-      }
-      out.emit(gl_sub(comb, res));
-      out.emit(gl_mul(bout, gl_sub(1, bout)));
-    }
-    break;
-  }
-  case G_U32_RANGE_CHECK: {
-    const uint32_t nl = g.p[0];
-    for (uint32_t i = 0; i < nl; i++) {
-      gl_t sum = 0;
-#pragma unroll 8
-      for (uint32_t j = 16; j-- > 0;) sum = gl_add(gl_mul_small(sum, 4), W(nl + 16 * i + j));
-      out.emit(gl_sub(sum, W(i)));
-#pragma unroll 8
-      for (uint32_t j = 0; j < 16; j++) out.emit(range4(W(nl + 16 * i + j)));
-    }
-    break;
-  }
-  case G_COMPARISON: {
-    const uint32_t nb = g.p[0], nc = g.p[1], cb = (nb + nc - 1) / nc;
-    const uint32_t fc = 4, sc = 4 + nc, dm = 4 + 2 * nc, eq = 4 + 3 * nc, im = 4 + 4 * nc, msb = 4 + 5 * nc;
-    gl_t a = 0, b = 0;
-    for (uint32_t i = nc; i-- > 0;) {
-      a = gl_add(gl_mul_small(a, 1u << cb), W(fc + i));
-      b = gl_add(gl_mul_small(b, 1u << cb), W(sc + i));
-    }
-    out.emit(gl_sub(a, W(0)));
-    out.emit(gl_sub(b, W(1)));
-    gl_t msd_so_far = 0;
-    for (uint32_t i = 0; i < nc; i++) {
-      gl_t f = W(fc + i), s = W(sc + i);
-      out.emit(range_product(f, 1u << cb));
-      out.emit(range_product(s, 1u << cb));
-      gl_t diff = gl_sub(s, f);
-      gl_t e = W(eq + i), iv = W(im + i);
-      out.emit(gl_sub(gl_mul(diff, W(dm + i)), gl_sub(1, e)));
-      out.emit(gl_mul(e, diff));
-      out.emit(gl_sub(iv, gl_mul(e, msd_so_far)));
-      msd_so_far = gl_add(iv, gl_mul(gl_sub(1, e), diff));
-    }
-    gl_t msd = W(3);
-    out.emit(gl_sub(msd, msd_so_far));
-    gl_t bits = 0;
-    for (uint32_t i = 0; i < cb + 1; i++) {
-      gl_t bt = W(msb + i);
-      out.emit(gl_mul(bt, gl_sub(1, bt)));
-    }
-    for (uint32_t i = cb + 1; i-- > 0;) bits = gl_add(gl_dbl(bits), W(msb + i));
-    out.emit(gl_sub(gl_add(msd, 1ULL << cb), bits));
-    out.emit(gl_sub(W(2), W(msb + cb)));
-    break;
-  }
-  case G_POSEIDON:
-    if constexpr (POSEIDON) {
-    // plonky2 gates/poseidon.rs.  Partial rounds in plain form: the S-box inputs (the only
-    // non-linear points) equal those of upstream's fast factorisation, so all 123 constraint
-    // values coincide.  Wires: in 0..11, out 12..23, swap 24, delta 25..28, full-0 S-box
-    // inputs 29.. (rounds 1-3), partial 65.., full-1 87..
-    gl_t st[12];
-    const gl_t swap = W(24);
-    out.emit(gl_mul(swap, gl_sub(swap, 1)));
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const gl_t l = W(i), r = W(i + 4), dl = W(25 + i);
-      out.emit(gl_sub(gl_mul(swap, gl_sub(r, l)), dl));
-      st[i] = gl_add(l, dl);
-      st[i + 4] = gl_sub(r, dl);
-    }
-#pragma unroll
-    for (int i = 8; i < 12; i++) st[i] = W(i);
-#pragma unroll 1
-    for (int r = 0; r < 30; r++) {
-#pragma unroll
-      for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], c_poseidon_rc[12 * r + i]);
-      const bool full = r < 4 || r >= 26;
-      if (full) {
-        if (r != 0) {
-          const uint32_t base = r < 4 ? 29 + 12 * (r - 1) : 87 + 12 * (r - 26);
-#pragma unroll
-          for (int i = 0; i < 12; i++) {
-            const gl_t sb = W(base + i);
-            out.emit(gl_sub(st[i], sb));
-            st[i] = sb;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 12; i++) st[i] = poseidon_sbox(st[i]);
-      } else {
-        const gl_t sb = W(65 + (r - 4));
-        out.emit(gl_sub(st[0], sb));
-        st[0] = poseidon_sbox(sb);
-      }
-      poseidon_mds(st);
-    }
-#pragma unroll
-    for (int i = 0; i < 12; i++) out.emit(gl_sub(st[i], W(12 + i)));
-    }
-    break;
-  default:
-    break;
-  }
-}
-
 // grid: x = k blocks, y = coset
 template <bool POSEIDON>
 __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
@@ -484,14 +232,11 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
     const GateDesc g = a.gates[gi];
     if (g.num_constraints == 0) continue;
     const gl_t s = cs[(size_t)g.sel_index * n];
-    gl_t f = 1;
-    for (uint32_t i = g.group_start; i < g.group_end; i++)
-      if (i != gi) f = gl_mul(f, gl_sub((gl_t)i, s));
-    if (a.num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFULL, s));
+    const gl_t f = gate_filter<BaseOps>(g, gi, a.num_selectors, s);
     out.acc0 = 0;
     out.acc1 = 0;
     out.t = t_gates;
-    eval_gate<POSEIDON>(g, W, LC, a.pi_hash, out);
+    eval_gate<BaseOps, POSEIDON>(g, W, LC, a.pi_hash, c_poseidon_rc, out);
     tot0 = gl_add(tot0, gl_mul(f, out.acc0));
     tot1 = gl_add(tot1, gl_mul(f, out.acc1));
   }

@@ -192,6 +192,7 @@ struct p2gpu_circuit {
   // knobs
   uint64_t pow_hint = UINT64_MAX;
   int profile = 0;
+  int self_check = 1;
   std::map<std::string, KernelStat> kstats;
   std::vector<PendingEv> pending;
   std::vector<hipEvent_t> event_pool;
@@ -340,6 +341,64 @@ void path_positions(const Batch &b, uint32_t C, unsigned lgC, size_t m0, unsigne
     m >>= 1;
   }
   (void)C;
+}
+
+// The verifier's plonk identity at zeta, on the opened values (plonk/verifier.rs
+// verify_with_challenges + vanishing_poly.rs eval_vanishing_poly over the extension):
+//   vanishing_c(zeta) == Z_H(zeta) * sum_m zeta^(n m) * t_{c,m}(zeta)        for each challenge c.
+// It fails exactly when the witness does not satisfy the circuit (with overwhelming
+// probability); upstream only finds that out in its witness generator, which stays in Rust.
+struct CollectOut {
+  std::vector<ext_t> *v;
+  void emit(ext_t c) { v->push_back(c); }
+};
+bool plonk_identity_holds(const p2gpu_circuit *c, const std::vector<ext_t> &op, const gl_t *betas, const gl_t *gammas,
+                          const gl_t *alphas, ext_t zeta, const gl_t pih[4]) {
+  const uint32_t K = c->K, R = c->R, W = c->W, NC = c->NC, QF = c->QF, PP = c->PP, nchunks = c->nchunks;
+  const uint32_t ncs = NC + R, nzp = K * (1 + PP), nall = ncs + W + nzp + K * QF;
+  const ext_t *o_const = op.data(), *o_sig = o_const + NC, *o_wires = o_sig + R, *o_zs = o_wires + W;
+  const ext_t *o_pp = o_zs + K, *o_quot = o_pp + K * PP, *o_zs_next = op.data() + nall;
+  ext_t zn = zeta;
+  for (uint32_t i = 0; i < c->d; i++) zn = ext_mul(zn, zn);
+  const ext_t z_h = ext_sub(zn, ext_from(1));
+  const ext_t l0 = ext_mul(z_h, ext_inv(ext_scale(ext_sub(zeta, ext_from(1)), (gl_t)c->n)));
+  std::vector<ext_t> terms;
+  for (uint32_t k = 0; k < K; k++) terms.push_back(ext_mul(l0, ext_sub(o_zs[k], ext_from(1))));
+  for (uint32_t k = 0; k < K; k++)
+    for (uint32_t m = 0; m < nchunks; m++) {
+      const ext_t prev = m == 0 ? o_zs[k] : o_pp[k * PP + m - 1];
+      const ext_t next = m == nchunks - 1 ? o_zs_next[k] : o_pp[k * PP + m];
+      ext_t np = ext_from(1), dp = ext_from(1);
+      for (uint32_t j = m * QF; j < (m + 1) * QF && j < R; j++) {
+        const ext_t s_id = ext_scale(zeta, c->k_is[j]);
+        np = ext_mul(np, ext_add(ext_add(o_wires[j], ext_scale(s_id, betas[k])), ext_from(gammas[k])));
+        dp = ext_mul(dp, ext_add(ext_add(o_wires[j], ext_scale(o_sig[j], betas[k])), ext_from(gammas[k])));
+      }
+      terms.push_back(ext_sub(ext_mul(prev, np), ext_mul(next, dp)));
+    }
+  std::vector<ext_t> gate_terms(c->max_gate_constraints, ext_from(0)), cons;
+  ext_t pih_e[4];
+  for (int i = 0; i < 4; i++) pih_e[i] = ext_from(pih[i]);
+  auto Wf = [&](uint32_t col) { return o_wires[col]; };
+  auto LC = [&](uint32_t i) { return o_const[c->num_selectors + i]; };
+  for (uint32_t gi = 0; gi < c->num_gates; gi++) {
+    const GateDesc &g = c->gates[gi];
+    if (!g.num_constraints) continue;
+    const ext_t f = gate_filter<ExtOps>(g, gi, c->num_selectors, o_const[g.sel_index]);
+    cons.clear();
+    CollectOut out{&cons};
+    eval_gate<ExtOps, true>(g, Wf, LC, pih_e, c->poseidon_rc, out);
+    for (size_t k = 0; k < cons.size() && k < gate_terms.size(); k++)
+      gate_terms[k] = ext_add(gate_terms[k], ext_mul(f, cons[k]));
+  }
+  terms.insert(terms.end(), gate_terms.begin(), gate_terms.end());
+  for (uint32_t k = 0; k < K; k++) {
+    ext_t van = ext_from(0), qz = ext_from(0);
+    for (size_t t = terms.size(); t-- > 0;) van = ext_add(ext_scale(van, alphas[k]), terms[t]);
+    for (uint32_t m = QF; m-- > 0;) qz = ext_add(ext_mul(qz, zn), o_quot[k * QF + m]);
+    if (!ext_eq(van, ext_mul(z_h, qz))) return false;
+  }
+  return true;
 }
 
 int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
@@ -500,6 +559,10 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     }
   }
   TRACE(c, "openings");
+  if (c->self_check && !plonk_identity_holds(c, op, betas, gammas, alphas, zeta, pih)) {
+    set_err("witness does not satisfy the circuit: the plonk identity fails at zeta (vanishing != Z_H * quotient)");
+    return P2GPU_E_UNSATISFIED;
+  }
   for (size_t j = 0; j < nall + K; j++) ch.observe_ext(op[j]);
   t0 = now_ms();
   T.openings_ms = t0 - t1;
@@ -1101,6 +1164,7 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) {
   if (!c || !key) return P2GPU_E_ARG;
   std::string k(key);
   if (k == "pow_hint") c->pow_hint = value;
+  else if (k == "self_check") c->self_check = (int)value;
   else if (k == "profile") {
     c->profile = (int)value;
     c->kstats.clear();

@@ -111,7 +111,9 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *public_
  * circuit's device; it is only read. */
 int p2gpu_prove_dev(p2gpu_circuit *c, const uint64_t *wires_dev, const uint64_t *public_inputs, uint32_t n_pi,
                     uint8_t *proof_out, size_t *proof_len, p2gpu_timings *opt_timings);
-/* optional knobs: "pow_hint" (u64; UINT64_MAX = grind), "profile" (0/1: time every
+/* optional knobs: "pow_hint" (u64; UINT64_MAX = grind), "self_check" (0/1, default 1: evaluate the
+ * verifier's plonk identity at zeta on the host before FRI and return P2GPU_E_UNSATISFIED when the
+ * witness does not satisfy the circuit; 0 = emit the proof anyway like upstream), "profile" (0/1: time every
  * kernel launch with HIP events on the launch stream; resets the statistics) */
 int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value);
 /* statistics accumulated while "profile" = 1, one entry per kernel symbol:

@@ -141,6 +141,12 @@ def test_unsatisfied_witness_gives_rejected_proof(pkg, orc, gpu):
     bad = wires.copy()
     bad[3, 5] = (int(bad[3, 5]) + 1) % P
     cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
+    # default: the library's self-check (the verifier's identity at zeta) refuses the witness
+    with pytest.raises(pkg.P2GpuError) as ei:
+        cd.prove(bad)
+    assert ei.value.code == -5
+    assert len(cd.prove(wires)) > 0  # the handle stays usable
+    cd.set("self_check", 0)
     proof = cd.prove(bad).to_bytes()
     assert proof == oc.prove(bad)[0]
     assert not oc.verify(proof)
@@ -187,5 +193,9 @@ def test_full_size_proof_is_accepted(pkg, orc, gpu, mix):
     # an unsatisfied witness at full size is rejected too
     w2 = wires.copy()
     w2[7, 12345] = (int(w2[7, 12345]) + 1) % P
+    with pytest.raises(pkg.P2GpuError) as ei:
+        cd.prove(w2)
+    assert ei.value.code == -5
+    cd.set("self_check", 0)
     assert not ov.verify(cd.prove(w2).to_bytes())
     cd.close()

@@ -91,7 +91,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    entry.build()
+    # one rank per node (re)builds; the others wait so that concurrent `make`s never race on the .so
+    if local_rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
     pkg = entry.load_package()
     lib = pkg.load_library()
     import ctypes

@@ -45,6 +45,15 @@ def test_ifft_and_lde_match_oracle(pkg, orc, gpu, d):
     assert np.array_equal(lde, np.stack([orc.coset_lde(r, 3) for r in exp]))
 
 
+def test_three_pass_transform(pkg, orc, gpu):
+    """2^21 points: the plan splits 21 = 12 + 5 + 4 layers (two strided passes)."""
+    v = _rand((1, 1 << 21), 21)
+    coeffs = pkg.ifft_batch(v)
+    assert np.array_equal(coeffs[0], orc.ntt(v[0], inverse=True))
+    lde = pkg.lde_batch(coeffs[:, : 1 << 21], 1)
+    assert np.array_equal(lde[0], orc.coset_lde(coeffs[0], 1))
+
+
 def test_large_transform_roundtrip(pkg, orc, gpu):
     """2^20 points (three LDS passes): iNTT against the oracle on one column and the identity
     LDE(iNTT(v))[8k] relation is checked through the oracle's LDE on the same coefficients."""
@@ -171,6 +180,21 @@ def test_error_paths(pkg, gpu):
         cd.prove(wires)
     cd.set("pow_hint", (1 << 64) - 1)
     assert len(cd.prove(wires)) > 0
+
+
+@pytest.mark.parametrize("d,mix", [(19, "ecdsa"), (21, "arith")])
+def test_larger_configs_are_accepted(pkg, orc, gpu, d, mix):
+    """BASELINE configs[3] / configs[4] sizes on ONE GPU: 2^22 LDE rows with every gate kind,
+    2^24 LDE rows (three-pass NTT, ~55 GB resident).  Property check: the verifier accepts."""
+    blob, wires = pkg.make_circuit(d, mix, 2)
+    cd = pkg.CircuitData(blob)
+    proof = cd.prove(wires)
+    ov = orc.OracleCircuit(blob, verifier_cap=cd.constants_sigmas_cap(), verifier_digest=cd.circuit_digest())
+    assert ov.verify(proof.to_bytes())
+    bad = bytearray(proof.to_bytes())
+    bad[len(bad) // 2] ^= 1
+    assert not ov.verify(bytes(bad))
+    cd.close()
 
 
 @pytest.mark.parametrize("mix", ["sha", "ecdsa"])

@@ -76,6 +76,9 @@ def main():
                     help="independent proofs in flight per GPU (separate circuit handles / HIP streams, one host "
                          "thread each): hides the latency-bound Merkle-tree tails and host round trips of one proof "
                          "behind the kernels of another; 1 = strictly one proof at a time")
+    ap.add_argument("--backend", default=os.environ.get("P2GPU_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the "
+                         "multi-rank flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bits", type=int, default=14)
     args = ap.parse_args()
@@ -87,12 +90,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if args.backend != "nccl":  # test mode: ranks may share a device
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     # one rank per node (re)builds; the others wait so that concurrent `make`s never race on the .so
-    if local_rank == 0:
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         entry.build()
     if world > 1:
         dist.barrier()
@@ -172,7 +180,7 @@ def main():
         gbps = (st["bytes"] / st["launches"]) / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(name)
         out = {
-            "metric": "proofs/sec at 2^20 LDE rows (prove latency = ms_per_step)",
+            "metric": f"proofs/sec at 2^{d + 3} LDE rows (prove latency = ms_per_step)",
             "value": total_proofs / dt,
             "unit": "proofs/sec",
             "n_gpus": world,

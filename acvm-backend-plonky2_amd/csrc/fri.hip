@@ -170,7 +170,7 @@ void pow_search(hipStream_t st, const gl_t state[12], uint32_t pos, uint32_t pow
 
 __global__ void gather_kernel(const uint64_t *addr, uint32_t count, gl_t *out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count) out[i] = *(const gl_t *)(uintptr_t)addr[i];
+  if (i < count) out[i] = addr[i] ? *(const gl_t *)(uintptr_t)addr[i] : 0;
 }
 void gather_u64(hipStream_t st, const uint64_t *addr, uint32_t count, gl_t *out) {
   if (!count) return;

@@ -37,12 +37,16 @@ struct NttPlan {
   gl_t *ptw = nullptr;   // device: packed per-round twiddle tables
   size_t table_len = 0;
 };
+// which global cosets a sharded launch covers: local index z <-> global coset first + z * stride
+struct CosetMap {
+  uint32_t first = 0, stride = 1;
+};
 NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse);
 void ntt_plan_destroy(NttPlan *p);
 // src [cols][n] (or [cosets][cols][n] when src_per_coset), dst [cosets][cols][n].
 // scale (DIT only): [cosets][n] multiplied into the input; post: multiplied into the output.
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
-               const gl_t *scale, gl_t post, bool src_per_coset);
+               const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm = CosetMap());
 void fill_powers(hipStream_t st, gl_t *out, gl_t root, uint32_t count);
 void fill_coset_scale(hipStream_t st, gl_t *out, gl_t shift, gl_t wN, uint32_t d, uint32_t cosets, gl_t mult);
 void bitrev_cols(hipStream_t st, const gl_t *in, gl_t *out, uint32_t d, uint32_t cols);
@@ -85,6 +89,8 @@ struct QuotArgs {
   const GateDesc *gates; // device copy
   gl_t *out;             // [K][cosets][n]
   uint32_t tw_shift, d, rate_bits, W, R, NC, num_selectors, K, QF, nchunks, PP, num_gates, nterms, has_poseidon;
+  uint32_t coset_first, coset_stride, ncosets;  // sharding: grid.y = local coset z, global r = first + z * stride;
+                                                // cs_lde/qconst are indexed by r, wires/zp/out by z
   gl_t betas[MAX_CHALLENGES], gammas[MAX_CHALLENGES];
   gl_t pi_hash[4];
   const gl_t *qconst;   // device [3][8]: coset shift 7 w_N^r | Z_H = 7^n w_8^r - 1 | 1 / Z_H
@@ -99,7 +105,7 @@ int poseidon_upload_constants();
 // inv_scale [C][n] = (1/s_r)^(bitrev p); out [K*C][n]: chunk polynomials
 // Q_m = 7^(-n m) / C * sum_r w_C^(-r m) P_r.
 void quotient_chunks(hipStream_t st, const gl_t *in, const gl_t *inv_scale, gl_t *out, uint32_t d, uint32_t K,
-                     uint32_t rate_bits, gl_t w_inv, gl_t gn_inv, gl_t rate_inv);
+                     uint32_t rate_bits, gl_t w_inv, gl_t gn_inv, gl_t rate_inv, uint32_t world = 1);
 
 // ---- fri.hip ----
 // pw[p] = base^(bitrev_d(p)) over the extension: out [2][n]
@@ -118,7 +124,7 @@ void fri_fold(hipStream_t st, const gl_t *in /*[2][n]*/, uint32_t d, uint32_t ar
 // proof of work: smallest w in [base, base + count) with leading zeros; result via atomicMin
 void pow_search(hipStream_t st, const gl_t state[12], uint32_t pos, uint32_t pow_bits, uint64_t base, uint64_t count,
                 unsigned long long *result);
-// gather: out[i] = *(const u64 *)addr[i] (absolute device addresses)
+// gather: out[i] = *(const u64 *)addr[i] (absolute device addresses; address 0 -> value 0)
 void gather_u64(hipStream_t st, const uint64_t *addr, uint32_t count, gl_t *out);
 
 }  // namespace p2

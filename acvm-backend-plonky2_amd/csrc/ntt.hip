@@ -120,6 +120,7 @@ struct PassArgs {
   uint32_t tb;        // log2 contiguous run; tile = 2^(a+tb)
   uint32_t cols;
   uint32_t src_single;  // 1: src has no coset dimension
+  uint32_t coset_first, coset_stride;  // global coset of grid.z = first + z * stride (indexes `scale`)
   uint32_t nrounds;
   uint32_t r[MAX_ROUNDS];       // layers per round, ascending tile bit
   uint32_t tw_off[MAX_ROUNDS];  // offset of the round's table in ptw
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(PassArgs A) {
   const uint32_t hi_base = hi << (A.s + A.a);
   const gl_t *src = A.src + ((size_t)(A.src_single ? 0 : coset) * A.cols + col) * n;
   gl_t *dst = A.dst + ((size_t)coset * A.cols + col) * n;
-  const gl_t *scale = A.scale ? A.scale + (size_t)coset * n : nullptr;
+  const gl_t *scale = A.scale ? A.scale + (size_t)(A.coset_first + coset * A.coset_stride) * n : nullptr;
   const uint32_t tsize = 1u << TB;
   if constexpr (TBC != 0) {
     constexpr int PER = 16, NT = (1 << TBC) / PER;
@@ -364,7 +365,7 @@ void ntt_plan_destroy(NttPlan *p) {
 }
 
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
-               const gl_t *scale, gl_t post, bool src_per_coset) {
+               const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm) {
   if (cols == 0) return;
   const uint32_t d = plan->d;
   const size_t np = plan->passes.size();
@@ -380,6 +381,8 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     A.s = ps.s; A.a = ps.a; A.tb = ps.tb;
     A.cols = cols;
     A.src_single = (i == 0 && !src_per_coset) ? 1 : 0;
+    A.coset_first = cm.first;
+    A.coset_stride = cm.stride;
     A.nrounds = ps.nrounds;
     for (int k = 0; k < MAX_ROUNDS; k++) { A.r[k] = ps.r[k]; A.tw_off[k] = ps.tw_off[k]; }
     const uint32_t TB = A.a + A.tb;

@@ -178,12 +178,13 @@ template <bool POSEIDON>
 __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
   const uint32_t n = 1u << a.d;
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t r = blockIdx.y;
+  const uint32_t z = blockIdx.y;                             // local coset
+  const uint32_t r = a.coset_first + z * a.coset_stride;     // global coset
   if (k >= n) return;
   const uint32_t ncs = a.NC + a.R, nzp = a.K * (1 + a.PP);
   const gl_t *cs = a.cs_lde + (size_t)r * ncs * n + k;
-  const gl_t *wl = a.wires_lde + (size_t)r * a.W * n + k;
-  const gl_t *zl = a.zp_lde + (size_t)r * nzp * n;  // indexed with explicit k (next row)
+  const gl_t *wl = a.wires_lde + (size_t)z * a.W * n + k;
+  const gl_t *zl = a.zp_lde + (size_t)z * nzp * n;  // indexed with explicit k (next row)
   const uint32_t kn = (k + 1) & (n - 1);
   const gl_t x = gl_mul(a.qconst[r], root_pow(a.tw, a.tw_shift, a.d, k));
   Consumer out;
@@ -241,31 +242,36 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
     tot1 = gl_add(tot1, gl_mul(f, out.acc1));
   }
   const gl_t zi = a.qconst[16 + r];
-  a.out[((size_t)0 * (1u << a.rate_bits) + r) * n + k] = gl_mul(tot0, zi);
-  if (a.K > 1) a.out[((size_t)1 * (1u << a.rate_bits) + r) * n + k] = gl_mul(tot1, zi);
+  a.out[((size_t)0 * a.ncosets + z) * n + k] = gl_mul(tot0, zi);
+  if (a.K > 1) a.out[((size_t)1 * a.ncosets + z) * n + k] = gl_mul(tot1, zi);
 }
 
 void quotient_eval(hipStream_t st, const QuotArgs &a) {
   const uint32_t n = 1u << a.d;
   const uint32_t threads = n >= 256 ? 256 : 64;
-  ProfScope ps(a.has_poseidon ? "quotient_kernel<true>" : "quotient_kernel<false>", 8.0 * (double)n * (1u << a.rate_bits) * (a.NC + a.R + a.W + a.K * (1 + a.PP) + 2.0 * a.K));
+  ProfScope ps(a.has_poseidon ? "quotient_kernel<true>" : "quotient_kernel<false>", 8.0 * (double)n * a.ncosets * (a.NC + a.R + a.W + a.K * (1 + a.PP) + 2.0 * a.K));
   if (a.has_poseidon)
-    hipLaunchKernelGGL(quotient_kernel<true>, dim3((n + threads - 1) / threads, 1u << a.rate_bits), dim3(threads), 0, st, a);
+    hipLaunchKernelGGL(quotient_kernel<true>, dim3((n + threads - 1) / threads, a.ncosets), dim3(threads), 0, st, a);
   else
-    hipLaunchKernelGGL(quotient_kernel<false>, dim3((n + threads - 1) / threads, 1u << a.rate_bits), dim3(threads), 0, st, a);
+    hipLaunchKernelGGL(quotient_kernel<false>, dim3((n + threads - 1) / threads, a.ncosets), dim3(threads), 0, st, a);
 }
 
 // in [K][C][n]: coefficients (bit-reversed storage) of the per-coset interpolants
 // in the variable y = x / s_r; out [K*C][n]: chunk polynomials Q_m, m < C.
+// `in` is [world][K][C/world][n]: the slice of rank q holds its cosets r = q + z * world (world = 1: [K][C][n])
 __global__ __launch_bounds__(256) void quotient_chunks_kernel(const gl_t *in, const gl_t *inv_scale, gl_t *out,
                                                              uint32_t d, uint32_t rate_bits, gl_t w_inv, gl_t gn_inv,
-                                                             gl_t rate_inv) {
+                                                             gl_t rate_inv, uint32_t world, uint32_t K) {
   const uint32_t n = 1u << d, C = 1u << rate_bits;
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t c = blockIdx.y;
   if (p >= n) return;
   gl_t P[8];
-  for (uint32_t r = 0; r < C; r++) P[r] = gl_mul(in[((size_t)c * C + r) * n + p], inv_scale[(size_t)r * n + p]);
+  const uint32_t own = C / world;
+  for (uint32_t r = 0; r < C; r++) {
+    const uint32_t q = r % world, z = r / world;
+    P[r] = gl_mul(in[(((size_t)q * K + c) * own + z) * n + p], inv_scale[(size_t)r * n + p]);
+  }
   gl_t wm = 1;       // w^-m
   gl_t scale = rate_inv;  // (7^-n)^m / C
   for (uint32_t m = 0; m < C; m++) {
@@ -280,12 +286,12 @@ __global__ __launch_bounds__(256) void quotient_chunks_kernel(const gl_t *in, co
   }
 }
 void quotient_chunks(hipStream_t st, const gl_t *in, const gl_t *inv_scale, gl_t *out, uint32_t d, uint32_t K,
-                     uint32_t rate_bits, gl_t w_inv, gl_t gn_inv, gl_t rate_inv) {
+                     uint32_t rate_bits, gl_t w_inv, gl_t gn_inv, gl_t rate_inv, uint32_t world) {
   const uint32_t n = 1u << d;
   const uint32_t threads = n >= 256 ? 256 : 64;
   ProfScope ps("quotient_chunks_kernel", 8.0 * (double)n * (1u << rate_bits) * (2.0 * K + 1));
   hipLaunchKernelGGL(quotient_chunks_kernel, dim3((n + threads - 1) / threads, K), dim3(threads), 0, st, in, inv_scale,
-                     out, d, rate_bits, w_inv, gn_inv, rate_inv);
+                     out, d, rate_bits, w_inv, gn_inv, rate_inv, world, K);
 }
 
 }  // namespace p2

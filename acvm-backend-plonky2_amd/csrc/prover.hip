@@ -137,6 +137,8 @@ struct DBuf {
 // one committed polynomial batch (plonky2 PolynomialBatch), GPU layout
 struct Batch {
   uint32_t cols = 0, d = 0;
+  uint32_t ncl = 0;   // cosets stored locally (all 2^rate_bits, or this rank's share when sharded)
+  CosetMap cm;        // local coset z <-> global coset cm.first + z * cm.stride
   DBuf<gl_t> coeffs;  // [cols][n], bit-reversed positions
   DBuf<gl_t> lde;     // [C][cols][n]
   DBuf<dig_t> dig;    // all tree levels, level l at level_off[l], layout [C][n >> l]
@@ -189,6 +191,11 @@ struct p2gpu_circuit {
   DBuf<uint64_t> gather_ptrs;
   DBuf<gl_t> gather_out;
   size_t gather_cap = 0;
+  // coset sharding across ranks (one process per GPU); world = 1: everything local
+  int shard_rank = 0, shard_world = 1;
+  p2gpu_allgather_fn shard_fn = nullptr;
+  void *shard_ctx = nullptr;
+  DBuf<gl_t> xchg_recv;
   // knobs
   uint64_t pow_hint = UINT64_MAX;
   int profile = 0;
@@ -245,38 +252,72 @@ void flush_kstats(p2gpu_circuit *c) {
 
 uint32_t brev(uint32_t x, unsigned bits) { return bitrev32(x, bits); }
 
-// allocate tree storage for [C][m0] leaf digests reduced to cap_per nodes per coset
-int tree_alloc(Batch &b, uint32_t C, size_t m0, size_t cap_per) {
+// all-gather over the ranks of a sharded proof (device buffers; the callback is the host side's
+// torch.distributed / RCCL all_gather_into_tensor).  recv = [world][bytes]
+int shard_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size_t bytes) {
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int rc = c->shard_fn(c->shard_ctx, (uint64_t)(uintptr_t)send_dev, (uint64_t)(uintptr_t)recv_dev, (uint64_t)bytes);
+  if (rc) {
+    set_err("all-gather callback failed (%d)", rc);
+    return P2GPU_E_DEVICE;
+  }
+  return 0;
+}
+
+// level offsets of a tree over [cosets][m0] leaf digests reduced to cap_per nodes per coset
+void tree_layout(Batch &b, uint32_t cosets, size_t m0, size_t cap_per) {
   b.level_off.clear();
   size_t off = 0;
   for (size_t m = m0;; m >>= 1) {
     b.level_off.push_back(off);
-    off += C * m;
+    off += (size_t)cosets * m;
     if (m <= cap_per) break;
   }
-  HIP_TRY(b.dig.alloc(off));
+}
+
+// allocate tree storage for [C][m0] leaf digests reduced to cap_per nodes per coset
+int tree_alloc(Batch &b, uint32_t C, size_t m0, size_t cap_per) {
+  tree_layout(b, C, m0, cap_per);
+  // the last level holds C * cap_per digests (or C * m0 when the leaves already are the cap)
+  size_t last_m = m0;
+  while (last_m > cap_per) last_m >>= 1;
+  const size_t total = b.level_off.back() + (size_t)C * last_m;
+  b.ncl = C;
+  HIP_TRY(b.dig.alloc(total));
   return 0;
 }
 
-// build tree levels above the leaf digests and fetch the cap in plonky2 order
 int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
-  const uint32_t C = c->C;
+  const uint32_t C = c->C, CL = b.ncl;
   size_t m = m0;
   const size_t cap_target = ((size_t)1 << c->cap_h) >> c->rate_bits;
   for (size_t l = 1; l < b.level_off.size(); l++) {
     if (m <= 4096) {  // the rest of the tree in one launch
-      merkle_tail(c->stream, b.dig.p + b.level_off[l - 1], C, (uint32_t)m, (uint32_t)cap_target);
+      merkle_tail(c->stream, b.dig.p + b.level_off[l - 1], CL, (uint32_t)m, (uint32_t)cap_target);
       m = cap_target;
       break;
     }
-    merkle_level(c->stream, b.dig.p + b.level_off[l - 1], b.dig.p + b.level_off[l], C, (uint32_t)m);
+    merkle_level(c->stream, b.dig.p + b.level_off[l - 1], b.dig.p + b.level_off[l], CL, (uint32_t)m);
     m >>= 1;
   }
-  size_t cap_per = m;
-  std::vector<dig_t> raw(C * cap_per);
-  HIP_TRY(hipMemcpyAsync(raw.data(), b.dig.p + b.level_off.back(), raw.size() * sizeof(dig_t), hipMemcpyDeviceToHost,
-                         c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t cap_per = m;
+  std::vector<dig_t> raw(C * cap_per);  // [global coset][cap_per]
+  if (CL == C) {
+    HIP_TRY(hipMemcpyAsync(raw.data(), b.dig.p + b.level_off.back(), raw.size() * sizeof(dig_t), hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  } else {
+    // coset r owns whole cap subtrees: exchange the CL * cap_per local roots (the path's only
+    // commitment-time collective: 16 x 25 B in total)
+    const size_t bytes = (size_t)CL * cap_per * sizeof(dig_t);
+    if (int rc = shard_allgather(c, b.dig.p + b.level_off.back(), c->xchg_recv.p, bytes)) return rc;
+    std::vector<dig_t> all((size_t)c->shard_world * CL * cap_per);
+    HIP_TRY(hipMemcpy(all.data(), c->xchg_recv.p, all.size() * sizeof(dig_t), hipMemcpyDeviceToHost));
+    for (int q = 0; q < c->shard_world; q++)
+      for (uint32_t z = 0; z < CL; z++)
+        for (size_t k = 0; k < cap_per; k++)
+          raw[((size_t)q + (size_t)z * c->shard_world) * cap_per + k] = all[((size_t)q * CL + z) * cap_per + k];
+  }
   unsigned lgC = c->rate_bits, lgp = 0;
   while (((size_t)1 << lgp) < cap_per) lgp++;
   b.cap.assign(C * cap_per, dig_t{});
@@ -288,10 +329,10 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
 // coefficients (bit-reversed storage) -> LDE on the 2^rate_bits cosets -> leaf digests -> tree
 int batch_commit_from_coeffs(p2gpu_circuit *c, Batch &b) {
   {
-    ntt_batch(c->stream, c->plan_fwd, b.coeffs.p, b.lde.p, b.cols, c->C, c->scale.p, 1, false);
+    ntt_batch(c->stream, c->plan_fwd, b.coeffs.p, b.lde.p, b.cols, b.ncl, c->scale.p, 1, false, b.cm);
   }
   {
-    hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, c->C, b.dig.p);
+    hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p);
   }
   TRACE(c, "  lde + leaf hash");
   return tree_build(c, b, c->n);
@@ -307,6 +348,8 @@ int batch_commit_from_values(p2gpu_circuit *c, Batch &b, const gl_t *vals_dev) {
 int batch_alloc(p2gpu_circuit *c, Batch &b, uint32_t cols) {
   b.cols = cols;
   b.d = c->d;
+  b.ncl = c->C;
+  b.cm = CosetMap();
   HIP_TRY(b.coeffs.alloc((size_t)cols * c->n));
   HIP_TRY(b.lde.alloc((size_t)cols * c->N));
   size_t cap_per = ((size_t)1 << c->cap_h) >> c->rate_bits;
@@ -332,12 +375,13 @@ struct Buf {
 void path_positions(const Batch &b, uint32_t C, unsigned lgC, size_t m0, unsigned lgm0, size_t j,
                     std::vector<size_t> &pos) {
   uint32_t r = brev((uint32_t)(j >> lgm0), lgC);
+  uint32_t z = (r - b.cm.first) / b.cm.stride;  // local coset (the caller owns r)
   uint32_t k = brev((uint32_t)(j & (m0 - 1)), lgm0);
   size_t m = m0;
   for (size_t l = 0; l + 1 < b.level_off.size(); l++) {
     size_t kk = k & (m - 1);
     size_t sib = kk ^ (m >> 1);
-    pos.push_back(b.level_off[l] + (size_t)r * m + sib);
+    pos.push_back(b.level_off[l] + (size_t)z * m + sib);
     m >>= 1;
   }
   (void)C;
@@ -492,6 +536,9 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     q.tw_shift = 0; q.d = d; q.rate_bits = c->rate_bits; q.W = W; q.R = R; q.NC = NC;
     q.num_selectors = c->num_selectors; q.K = K; q.QF = QF; q.nchunks = c->nchunks; q.PP = PP;
     q.num_gates = c->num_gates; q.nterms = nterms;
+    q.coset_first = c->wires.cm.first;
+    q.coset_stride = c->wires.cm.stride;
+    q.ncosets = c->wires.ncl;
     q.has_poseidon = 0;
     for (auto &g : c->gates)
       if (g.kind == G_POSEIDON) q.has_poseidon = 1;
@@ -507,11 +554,18 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     TRACE(c, "quotient_eval");
     // coset_ifft of size N = per-coset inverse transforms + cross-coset butterflies
     {
-      ntt_batch(st, c->plan_inv, c->qvals.p, c->qtmp.p, K * C, 1, nullptr, q.n_inv, false);
+      ntt_batch(st, c->plan_inv, c->qvals.p, c->qtmp.p, K * c->wires.ncl, 1, nullptr, q.n_inv, false);
     }
     {
-      quotient_chunks(st, c->qtmp.p, c->inv_scale.p, c->quot.coeffs.p, d, K, c->rate_bits, gl_inv(wC), gl_inv(gn),
-                      gl_inv((gl_t)C));
+      const gl_t *pr = c->qtmp.p;
+      if (c->shard_world > 1) {
+        // every rank needs all cosets' interpolants for the cross-coset butterflies: all-gather
+        // [K][C/world][n] per rank (2 * N * 8 B in total) straight between device buffers
+        if (int rc = shard_allgather(c, c->qtmp.p, c->qvals.p, (size_t)K * c->wires.ncl * n * sizeof(gl_t))) return rc;
+        pr = c->qvals.p;
+      }
+      quotient_chunks(st, pr, c->inv_scale.p, c->quot.coeffs.p, d, K, c->rate_bits, gl_inv(wC), gl_inv(gn),
+                      gl_inv((gl_t)C), (uint32_t)c->shard_world);
     }
     TRACE(c, "quotient_chunks");
   }
@@ -599,7 +653,8 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
       ntt_batch(st, c->plan_inv, c->fv.p, c->fri_coef[0].p, 2, 1, nullptr, gl_inv((gl_t)n), false);
     }
     if (c->n_steps > 0) {  // no reduction step (degree <= 2^5): the values are never committed
-      ntt_batch(st, c->plan_fwd, c->fri_coef[0].p, c->fri_vals[0].p, 2, C, c->scale.p, 1, false);
+      ntt_batch(st, c->plan_fwd, c->fri_coef[0].p, c->fri_vals[0].p, 2, c->fri_trees[0].ncl, c->scale.p, 1, false,
+                c->fri_trees[0].cm);
     }
   }
   TRACE(c, "fri final poly lde");
@@ -610,7 +665,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     const uint32_t ab = c->arity[s];
     Batch &tr = c->fri_trees[s];
     {
-      hash_fri_leaves(st, c->fri_vals[s].p, ds, C, ab, tr.dig.p);
+      hash_fri_leaves(st, c->fri_vals[s].p, ds, tr.ncl, ab, tr.dig.p);
     }
     if (int rc = tree_build(c, tr, ((size_t)1 << ds) >> ab)) return rc;
     ch.observe_cap(tr.cap);
@@ -685,36 +740,54 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     for (int w = 0; w < 4; w++) ptrs.push_back(base + 8 * w);
   };
   std::vector<size_t> pos;
+  const int world = c->shard_world, me = c->shard_rank;
+  size_t per_query = 0;
   for (size_t x : qidx) {
+    // every piece of query x lives in coset r = bitrev(top bits of x): one rank owns the query
+    const uint32_t rq = brev((uint32_t)(x >> d), lgC);
+    const bool mine = (int)(rq % (uint32_t)world) == me;
+    const size_t start = ptrs.size();
     for (int o = 0; o < 4; o++) {
       const Batch &b = *oracles[o];
-      uint32_t r = brev((uint32_t)(x >> d), lgC), k = brev((uint32_t)(x & (n - 1)), d);
+      const uint32_t r = rq, k = brev((uint32_t)(x & (n - 1)), d);
+      const uint32_t z = (r - b.cm.first) / b.cm.stride;
       for (uint32_t col = 0; col < b.cols; col++)
-        ptrs.push_back((uint64_t)(uintptr_t)(b.lde.p + ((size_t)r * b.cols + col) * n + k));
+        ptrs.push_back(mine ? (uint64_t)(uintptr_t)(b.lde.p + ((size_t)z * b.cols + col) * n + k) : 0);
       pos.clear();
-      path_positions(b, C, lgC, n, d, x, pos);
-      for (size_t p : pos) push_dig(b, p);
+      if (mine) path_positions(b, C, lgC, n, d, x, pos);
+      else pos.assign(b.level_off.size() - 1, 0);
+      for (size_t p : pos) {
+        if (mine) push_dig(b, p);
+        else for (int w = 0; w < 4; w++) ptrs.push_back(0);
+      }
     }
     size_t xi = x;
     uint32_t dcur = d;
     for (uint32_t s = 0; s < c->n_steps; s++) {
       const uint32_t ab = c->arity[s];
+      const Batch &tr = c->fri_trees[s];
       const size_t npc = (size_t)1 << dcur, per = npc >> ab;  // per-coset leaves
       const size_t li = xi >> ab;                              // leaf index (plonky2 order) in tree s
       const unsigned lgper = dcur - ab;
-      uint32_t r = brev((uint32_t)(li >> lgper), lgC), kl = brev((uint32_t)(li & (per - 1)), lgper);
-      const gl_t *v0 = c->fri_vals[s].p + (size_t)r * 2 * npc;
+      const uint32_t r = brev((uint32_t)(li >> lgper), lgC), kl = brev((uint32_t)(li & (per - 1)), lgper);
+      const uint32_t z = (r - tr.cm.first) / tr.cm.stride;
+      const gl_t *v0 = c->fri_vals[s].p + (size_t)z * 2 * npc;
       for (uint32_t t = 0; t < (1u << ab); t++) {
         size_t k = (size_t)brev(t, ab) * per + kl;
-        ptrs.push_back((uint64_t)(uintptr_t)(v0 + k));
-        ptrs.push_back((uint64_t)(uintptr_t)(v0 + npc + k));
+        ptrs.push_back(mine ? (uint64_t)(uintptr_t)(v0 + k) : 0);
+        ptrs.push_back(mine ? (uint64_t)(uintptr_t)(v0 + npc + k) : 0);
       }
       pos.clear();
-      path_positions(c->fri_trees[s], C, lgC, per, lgper, li, pos);
-      for (size_t p : pos) push_dig(c->fri_trees[s], p);
+      if (mine) path_positions(tr, C, lgC, per, lgper, li, pos);
+      else pos.assign(tr.level_off.size() - 1, 0);
+      for (size_t p : pos) {
+        if (mine) push_dig(tr, p);
+        else for (int w = 0; w < 4; w++) ptrs.push_back(0);
+      }
       xi = li;
       dcur -= ab;
     }
+    per_query = ptrs.size() - start;
   }
   if (ptrs.size() > c->gather_cap) {
     set_err("internal: gather buffer too small");
@@ -725,8 +798,20 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   {
     gather_u64(st, c->gather_ptrs.p, (uint32_t)ptrs.size(), c->gather_out.p);
   }
-  HIP_TRY(hipMemcpyAsync(gathered.data(), c->gather_out.p, ptrs.size() * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  if (world == 1) {
+    HIP_TRY(hipMemcpyAsync(gathered.data(), c->gather_out.p, ptrs.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  } else {
+    // each rank gathered the queries that fall into its cosets: exchange and pick every query
+    // from its owner
+    if (int rc = shard_allgather(c, c->gather_out.p, c->xchg_recv.p, ptrs.size() * 8)) return rc;
+    std::vector<gl_t> all((size_t)world * ptrs.size());
+    HIP_TRY(hipMemcpy(all.data(), c->xchg_recv.p, all.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t qi = 0; qi < qidx.size(); qi++) {
+      const uint32_t owner = brev((uint32_t)(qidx[qi] >> d), lgC) % (uint32_t)world;
+      memcpy(&gathered[qi * per_query], &all[(size_t)owner * ptrs.size() + qi * per_query], per_query * 8);
+    }
+  }
 
   // ---- serialise: plonky2 ProofWithPublicInputs::to_bytes ----
   Buf out;
@@ -794,7 +879,7 @@ void circuit_release(p2gpu_circuit *c) {
   for (auto &b : c->fri_coef) b.release();
   for (auto &b : c->fri_vals) b.release();
   for (auto &b : c->fri_trees) b.release();
-  c->pow_result.release(); c->gather_ptrs.release(); c->gather_out.release();
+  c->pow_result.release(); c->gather_ptrs.release(); c->gather_out.release(); c->xchg_recv.release();
   ntt_plan_destroy(c->plan_inv);
   ntt_plan_destroy(c->plan_fwd);
   for (auto *p : c->fri_plans)
@@ -1172,6 +1257,40 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) {
     set_err("unknown knob %s", key);
     return P2GPU_E_ARG;
   }
+  return P2GPU_OK;
+}
+
+int p2gpu_circuit_set_shard(p2gpu_circuit *c, int rank, int world, p2gpu_allgather_fn fn, void *ctx) {
+  if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn) || (c->C % (uint32_t)world) != 0) {
+    set_err("bad shard configuration: rank %d of %d (cosets %u)", rank, world, c ? c->C : 0u);
+    return P2GPU_E_ARG;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  c->shard_rank = rank;
+  c->shard_world = world;
+  c->shard_fn = fn;
+  c->shard_ctx = ctx;
+  const uint32_t ncl = c->C / (uint32_t)world;
+  const size_t cap_per = ((size_t)1 << c->cap_h) >> c->rate_bits;
+  CosetMap cm;
+  cm.first = (uint32_t)rank;
+  cm.stride = (uint32_t)world;
+  // the per-proof oracles and the first FRI tree are sharded by coset; the constants/sigmas oracle
+  // and the later (16x smaller) FRI steps stay complete on every rank
+  Batch *bs[3] = {&c->wires, &c->zp, &c->quot};
+  for (Batch *b : bs) {
+    b->ncl = ncl;
+    b->cm = cm;
+    tree_layout(*b, ncl, c->n, cap_per);
+  }
+  if (c->n_steps > 0) {
+    Batch &t0 = c->fri_trees[0];
+    t0.ncl = ncl;
+    t0.cm = cm;
+    tree_layout(t0, ncl, c->n >> c->arity[0], cap_per);
+  }
+  c->xchg_recv.release();
+  if (world > 1) HIP_TRY(c->xchg_recv.alloc((size_t)world * c->gather_cap + 64));
   return P2GPU_OK;
 }
 

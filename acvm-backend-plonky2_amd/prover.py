@@ -41,6 +41,17 @@ class _Timings(ctypes.Structure):
     ]
 
 
+_ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64)
+
+
+class _DevBytes:
+    """Zero-copy view of a device buffer for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2}
+
+
 def lib_path():
     return os.path.join(_HERE, "libp2gpu.so")
 
@@ -75,6 +86,7 @@ def load_library():
     lib.p2gpu_prove.argtypes = [vp, vp, vp, ctypes.c_uint32, u8p, ctypes.POINTER(sz), ctypes.POINTER(_Timings)]
     lib.p2gpu_prove_dev.argtypes = lib.p2gpu_prove.argtypes
     lib.p2gpu_circuit_set.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64]
+    lib.p2gpu_circuit_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int, _ALLGATHER_FN, vp]
     lib.p2gpu_kernel_stats.argtypes = [vp, ctypes.c_char_p, vp, vp, vp, ctypes.c_int]
     lib.p2gpu_ifft_batch.argtypes = [vp, sz, ctypes.c_uint, vp]
     lib.p2gpu_lde_batch.argtypes = [vp, sz, ctypes.c_uint, ctypes.c_uint, vp]
@@ -158,6 +170,39 @@ class CircuitData:
 
     def set(self, key, value):
         _check(self._lib.p2gpu_circuit_set(self._h, key.encode(), ctypes.c_uint64(value)))
+
+    def set_shard(self, rank, world, group=None):
+        """Coset-shard every following proof over the `world` ranks of `group` (one process per
+        GPU; torch.distributed must be initialised).  The library hands device buffers to the
+        all-gather below: with the nccl backend (= RCCL over xGMI) they are gathered in place,
+        with gloo (CPU tests) they are staged through host tensors."""
+        import torch
+        import torch.distributed as dist
+
+        if world > 1:
+            backend = dist.get_backend(group)
+
+            def _allgather(_ctx, send, recv, nbytes):
+                try:
+                    s = torch.as_tensor(_DevBytes(send, nbytes), device="cuda")
+                    r = torch.as_tensor(_DevBytes(recv, nbytes * world), device="cuda")
+                    if backend == "nccl":
+                        dist.all_gather_into_tensor(r, s, group=group)
+                    else:
+                        out = torch.empty(nbytes * world, dtype=torch.uint8)
+                        dist.all_gather_into_tensor(out, s.cpu(), group=group)
+                        r.copy_(out)
+                    torch.cuda.synchronize()
+                    return 0
+                except Exception as e:  # never let an exception cross the C ABI
+                    self._shard_error = e
+                    return -1
+
+            self._shard_cb = _ALLGATHER_FN(_allgather)  # keep alive as long as the handle
+        else:
+            self._shard_cb = _ALLGATHER_FN(0)
+        _check(self._lib.p2gpu_circuit_set_shard(self._h, rank, world, self._shard_cb, None))
+        self.shard = (rank, world)
 
     def kernel_stats(self):
         cap = 64

@@ -121,6 +121,17 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value);
  * launch count.  Returns the number of entries written (<= cap). */
 int p2gpu_kernel_stats(p2gpu_circuit *c, char *names, double *ms, double *bytes, uint64_t *launches, int cap);
 
+/* ---- one proof over several GPUs (one process per GPU) --------------------------------------
+ * Coset sharding: rank q of `world` keeps the LDE cosets {r : r mod world == q}
+ * of the per-proof oracles -- whole Merkle-cap subtrees -- and only three things are exchanged
+ * per proof, all through `fn` (an all-gather the host side implements with torch.distributed /
+ * RCCL on the device buffers it is handed): the cap entries of each commitment (16 x 25 B), the
+ * per-coset quotient interpolants (2 * N * 8 B), and the query openings.  Every rank runs the
+ * transcript and returns the same proof bytes.  `fn(ctx, send_dev, recv_dev, bytes)` must gather
+ * `bytes` from every rank's send buffer into recv_dev[rank * bytes ...] and return 0 when done. */
+typedef int (*p2gpu_allgather_fn)(void *ctx, uint64_t send_dev, uint64_t recv_dev, uint64_t bytes_per_rank);
+int p2gpu_circuit_set_shard(p2gpu_circuit *c, int rank, int world, p2gpu_allgather_fn fn, void *ctx);
+
 /* stage-level operators (host buffers in/out; used by the parity tests) */
 /* values [ncols][2^d] -> coefficients [ncols][2^d], natural order */
 int p2gpu_ifft_batch(const uint64_t *vals, size_t ncols, unsigned d, uint64_t *coeffs_out);

@@ -223,3 +223,61 @@ def test_full_size_proof_is_accepted(pkg, orc, gpu, mix):
     cd.set("self_check", 0)
     assert not ov.verify(cd.prove(w2).to_bytes())
     cd.close()
+
+
+# ---- one proof sharded over two ranks (coset sharding) -----------------------------
+def _shard_worker(rank, world, port, d, mix, npi, q):
+    import os
+    import sys
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as entry
+
+    torch.cuda.set_device(0)  # both ranks share the one GPU of the test box; collectives over gloo
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = entry.load_package()
+    out = pkg.make_circuit(d, mix, 31, num_public_inputs=npi)
+    blob, wires, pis = (out + ((),))[:3] if npi == 0 else out
+    cd = pkg.CircuitData(blob)
+    cd.set_shard(rank, world)
+    p1 = cd.prove(wires, public_inputs=pis).to_bytes()
+    p2 = cd.prove(torch.from_numpy(wires.view(np.int64)).cuda(), public_inputs=pis).to_bytes()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, p1, p1 == p2))
+
+
+@pytest.mark.parametrize("world,d,mix,npi", [(2, 8, "ecdsa", 0), (2, 13, "sha", 4), (4, 9, "arith", 0), (8, 10, "ecdsa", 0)])
+def test_coset_sharded_proof_matches_oracle(pkg, orc, gpu, world, d, mix, npi):
+    """`world` processes (one per GPU on a real node; here they share the GPU and talk gloo) each
+    keep 8/world LDE cosets of the per-proof oracles; caps, quotient interpolants and query
+    openings are all-gathered.  Every rank must return the oracle's proof bytes."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, d, mix, npi, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    out = pkg.make_circuit(d, mix, 31, num_public_inputs=npi)
+    blob, wires = out[0], out[1]
+    pis = out[2] if npi else ()
+    expect, _ = orc.OracleCircuit(blob).prove(wires, public_inputs=pis)
+    for rank, proof, same in res:
+        assert same, rank
+        assert proof == expect, rank

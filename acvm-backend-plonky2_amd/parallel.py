@@ -9,8 +9,9 @@ Two ways the `prove` path spreads over the GPUs of a node:
   plonky2's leaf index is bitrev(8k + r) = bitrev3(r) * n + bitrev(k), coset r owns whole cap
   subtrees -- cap entries 2*bitrev3(r) and 2*bitrev3(r)+1 -- so the only exchange a commitment
   needs is an all-gather of 16 x 25-byte cap entries (`all_gather_cap`), after which every rank
-  runs the Fiat-Shamir transcript replicated.  The kernels for the sharded LDE are the same
-  per-coset kernels (grid.z = coset); wiring them to this exchange is the next multi-GPU step.
+  runs the Fiat-Shamir transcript replicated.  This mode is implemented inside the library
+  (`CircuitData.set_shard(rank, world)` -> p2gpu_circuit_set_shard); the helpers below state the
+  ownership map and are what the CPU-only gloo test exercises.
 """
 import numpy as np
 

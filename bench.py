@@ -76,6 +76,10 @@ def main():
                     help="independent proofs in flight per GPU (separate circuit handles / HIP streams, one host "
                          "thread each): hides the latency-bound Merkle-tree tails and host round trips of one proof "
                          "behind the kernels of another; 1 = strictly one proof at a time")
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+                    help="N > 1: `replicas` = independent proofs per GPU (throughput, weak scaling, default); "
+                         "`sharded` = ONE proof coset-sharded over the N GPUs (latency, strong scaling; RCCL "
+                         "all-gathers of caps / quotient interpolants / query openings)")
     ap.add_argument("--backend", default=os.environ.get("P2GPU_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the "
                          "multi-rank flow on a box with fewer GPUs than ranks)")
@@ -112,9 +116,12 @@ def main():
 
     d, mix = args.degree_bits, args.mix
     # every rank proves its own witness of the same circuit shape (independent proofs)
-    blob, wires = pkg.make_circuit(d, mix, seed=1 + rank)
-    S = max(1, min(args.in_flight, args.steps))
+    sharded = args.mode == "sharded" and world > 1
+    blob, wires = pkg.make_circuit(d, mix, seed=1 if sharded else 1 + rank)
+    S = 1 if sharded else max(1, min(args.in_flight, args.steps))
     cds = [pkg.CircuitData(blob) for _ in range(S)]
+    if sharded:
+        cds[0].set_shard(rank, world)
     wires_dev = torch.from_numpy(wires.view(np.int64)).cuda()
     torch.cuda.synchronize()
 
@@ -174,7 +181,7 @@ def main():
     cd = cds[0]
 
     if rank == 0:
-        total_proofs = world * args.steps
+        total_proofs = args.steps if sharded else world * args.steps
         name, st = max(stats.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = st["ms"] / st["launches"]
         gbps = (st["bytes"] / st["launches"]) / (avg_ms * 1e-3) / 1e9
@@ -188,7 +195,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "u64 (Goldilocks field, p = 2^64 - 2^32 + 1)",
             "data": "synthetic",
@@ -196,8 +203,10 @@ def main():
                 "workload": f"synth(d={d},{mix}): {1 << d} gates -> 2^{d + 3} LDE rows, 234 wires / 80 routed, "
                             f"KeccakGoldilocksConfig, rate 8, cap 2^4, 28 queries, 16 PoW bits (BASELINE configs[2] shape)",
                 "degree_bits": d, "lde_rows": 1 << (d + 3), "mix": mix,
-                "parallelism": f"replicas x{world} (independent proofs per GPU, no data-path collective), "
-                               f"{S} proofs in flight per GPU",
+                "parallelism": (f"one proof coset-sharded over {world} GPUs (8/{world} LDE cosets each; all-gather of caps, "
+                                f"quotient interpolants, query openings)" if sharded else
+                                f"replicas x{world} (independent proofs per GPU, no data-path collective), "
+                                f"{S} proofs in flight per GPU"),
                 "proof_bytes": len(proof),
                 "witness": "resident in HBM (p2gpu_prove_dev); proof bytes returned to host",
             },

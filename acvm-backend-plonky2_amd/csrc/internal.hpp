@@ -107,6 +107,11 @@ int poseidon_upload_constants();
 void quotient_chunks(hipStream_t st, const gl_t *in, const gl_t *inv_scale, gl_t *out, uint32_t d, uint32_t K,
                      uint32_t rate_bits, gl_t w_inv, gl_t gn_inv, gl_t rate_inv, uint32_t world = 1);
 
+// ---- witness.hip ----
+// row-local generators: derive every gate-internal wire from the gate's input wires, in place
+void fill_witness(hipStream_t st, gl_t *wires, const uint8_t *row_gate, const GateDesc *gates, const gl_t *gconsts,
+                  const gl_t *prc, uint32_t d, uint32_t ngc, uint32_t num_wires);
+
 // ---- fri.hip ----
 // pw[p] = base^(bitrev_d(p)) over the extension: out [2][n]
 void ext_powers_bitrev(hipStream_t st, ext_t base, uint32_t d, gl_t *out);

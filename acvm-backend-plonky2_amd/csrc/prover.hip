@@ -177,6 +177,8 @@ struct p2gpu_circuit {
   // tables
   DBuf<gl_t> tw_fwd, tw_inv, scale, inv_scale, d_kis, d_sigmas, fri_scale, qconst;
   DBuf<GateDesc> d_gates;
+  DBuf<uint8_t> d_row_gate;   // [n] gate index of every row (from the selector columns)
+  DBuf<gl_t> d_gconsts, d_prc; // gate-constant columns [NC - num_selectors][n]; Poseidon round constants
   NttPlan *plan_inv = nullptr, *plan_fwd = nullptr;  // size n: values->coeffs (DIF, w^-1), coeffs->values (DIT)
   std::vector<NttPlan *> fri_plans;                   // DIT plans of the FRI step sizes
   // oracles
@@ -871,7 +873,8 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
 
 void circuit_release(p2gpu_circuit *c) {
   c->tw_fwd.release(); c->tw_inv.release(); c->scale.release(); c->inv_scale.release(); c->d_kis.release();
-  c->d_sigmas.release(); c->fri_scale.release(); c->d_gates.release(); c->qconst.release(); c->qconst.release();
+  c->d_sigmas.release(); c->fri_scale.release(); c->d_gates.release(); c->qconst.release();
+  c->d_row_gate.release(); c->d_gconsts.release(); c->d_prc.release(); c->qconst.release();
   c->cs.release(); c->wires.release(); c->zp.release(); c->quot.release();
   c->wires_vals.release(); c->zp_vals.release(); c->cp.release(); c->rowprod.release(); c->scan_tmp.release();
   c->apow.release(); c->qvals.release(); c->qtmp.release(); c->pw.release(); c->partial.release();
@@ -1121,6 +1124,28 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   CK(hipMemcpyAsync(c->d_sigmas.p, sigmas, 8 * (size_t)c->R * n, hipMemcpyHostToDevice, st), "copy sigmas");
   if (c->num_gates)
     CK(hipMemcpyAsync(c->d_gates.p, c->gates.data(), sizeof(GateDesc) * c->num_gates, hipMemcpyHostToDevice, st), "copy gates");
+  {
+    // row -> gate (the one selector column that is not UNUSED holds the index) and the gate
+    // constants, for the row-local witness generators (p2gpu_fill_witness)
+    std::vector<uint8_t> rg(n, 0);
+    for (size_t row = 0; row < n; row++) {
+      uint32_t gi = 0;
+      for (uint32_t s = 0; s < c->num_selectors; s++) {
+        gl_t v = constants[(size_t)s * n + row];
+        if (c->num_selectors == 1 || v != 0xFFFFFFFFULL) gi = (uint32_t)v;
+      }
+      if (gi >= c->num_gates) return fail(P2GPU_E_BLOB, "selector column holds an unknown gate index");
+      rg[row] = (uint8_t)gi;
+    }
+    const uint32_t ngc = c->NC - c->num_selectors;
+    CK(c->d_row_gate.alloc(n), "alloc row_gate");
+    CK(c->d_gconsts.alloc((size_t)(ngc ? ngc : 1) * n), "alloc gconsts");
+    CK(c->d_prc.alloc(360), "alloc prc");
+    CK(hipMemcpy(c->d_row_gate.p, rg.data(), n, hipMemcpyHostToDevice), "copy row_gate");
+    if (ngc)
+      CK(hipMemcpy(c->d_gconsts.p, constants + (size_t)c->num_selectors * n, 8 * (size_t)ngc * n, hipMemcpyHostToDevice), "copy gconsts");
+    CK(hipMemcpy(c->d_prc.p, c->poseidon_rc, sizeof c->poseidon_rc, hipMemcpyHostToDevice), "copy prc");
+  }
   if (batch_alloc(c, c->cs, ncs) || batch_alloc(c, c->wires, c->W) || batch_alloc(c, c->zp, nzp) || batch_alloc(c, c->quot, nq)) {
     std::string keep = g_err;
     circuit_release(c);
@@ -1308,6 +1333,30 @@ int p2gpu_kernel_stats(p2gpu_circuit *c, char *names, double *ms, double *bytes,
     i++;
   }
   return i;
+}
+
+int p2gpu_fill_witness(p2gpu_circuit *c, uint64_t *wires_dev) {
+  if (!c || !wires_dev) return P2GPU_E_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  fill_witness(c->stream, wires_dev, c->d_row_gate.p, c->d_gates.p, c->d_gconsts.p, c->d_prc.p, c->d, c->NC - c->num_selectors,
+               c->W);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return P2GPU_OK;
+}
+
+int p2gpu_prove_routed(p2gpu_circuit *c, const uint64_t *routed, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
+                       size_t *proof_len, p2gpu_timings *tm) {
+  if (!c || !routed || !proof_out || !proof_len) return P2GPU_E_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  double t0 = now_ms();
+  // only the routed columns cross PCIe; every other column is gate-internal and derived on the GPU
+  HIP_TRY(hipMemcpyAsync(c->wires_vals.p, routed, 8 * (size_t)c->R * c->n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->wires_vals.p + (size_t)c->R * c->n, 0, 8 * (size_t)(c->W - c->R) * c->n, c->stream));
+  fill_witness(c->stream, c->wires_vals.p, c->d_row_gate.p, c->d_gates.p, c->d_gconsts.p, c->d_prc.p, c->d,
+               c->NC - c->num_selectors, c->W);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  double h2d = now_ms() - t0;
+  return prove_impl(c, c->wires_vals.p, pis, n_pi, proof_out, proof_len, tm, h2d);
 }
 
 int p2gpu_prove_dev(p2gpu_circuit *c, const uint64_t *wires_dev, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,

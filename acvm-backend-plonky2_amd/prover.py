@@ -85,6 +85,8 @@ def load_library():
     lib.p2gpu_proof_size_bound.restype = sz
     lib.p2gpu_prove.argtypes = [vp, vp, vp, ctypes.c_uint32, u8p, ctypes.POINTER(sz), ctypes.POINTER(_Timings)]
     lib.p2gpu_prove_dev.argtypes = lib.p2gpu_prove.argtypes
+    lib.p2gpu_prove_routed.argtypes = lib.p2gpu_prove.argtypes
+    lib.p2gpu_fill_witness.argtypes = [vp, vp]
     lib.p2gpu_circuit_set.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64]
     lib.p2gpu_circuit_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int, _ALLGATHER_FN, vp]
     lib.p2gpu_kernel_stats.argtypes = [vp, ctypes.c_char_p, vp, vp, vp, ctypes.c_int]
@@ -240,6 +242,27 @@ class CircuitData:
         _check(rc)
         t = {f: getattr(tm, f) for f, _ in _Timings._fields_}
         return ProofWithPublicInputs(out[:plen.value].tobytes(), t)
+
+    def fill_witness(self, wires_dev):
+        """Run the gates' row-local generators on a device wire matrix (torch tensor, in place)."""
+        if not (hasattr(wires_dev, "data_ptr") and getattr(wires_dev, "is_cuda", False)):
+            raise P2GpuError(-7, "fill_witness needs a torch tensor on the GPU")
+        if wires_dev.numel() != self.num_wires * self.degree or not wires_dev.is_contiguous():
+            raise P2GpuError(-7, "wires tensor must be contiguous [num_wires][degree]")
+        _check(self._lib.p2gpu_fill_witness(self._h, ctypes.c_void_p(wires_dev.data_ptr())))
+        return wires_dev
+
+    def prove_routed(self, routed, public_inputs=()):
+        """Prove from the routed columns only ([num_routed_wires][degree], host): gate-internal
+        columns are derived on the GPU by the row-local generators."""
+        pis = _u64(np.array(list(public_inputs), dtype=np.uint64))
+        r = _u64(routed)
+        out = np.zeros(self._bound, dtype=np.uint8)
+        plen = ctypes.c_size_t(out.nbytes)
+        tm = _Timings()
+        _check(self._lib.p2gpu_prove_routed(self._h, r.ctypes.data, pis.ctypes.data, len(pis), out.ctypes.data,
+                                            ctypes.byref(plen), ctypes.byref(tm)))
+        return ProofWithPublicInputs(out[:plen.value].tobytes(), {f: getattr(tm, f) for f, _ in _Timings._fields_})
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -13,6 +13,9 @@
  *                             plonky2-backend/src/actions/prove_action.rs:91-97,
  *                             after witness generation (input = full wire matrix)
  *   p2gpu_prove_dev        <- same, wire matrix already resident in HBM
+ *   p2gpu_fill_witness / p2gpu_prove_routed
+ *                          <- the row-local tail of `generate_partial_witness`: the gates' own
+ *                             SimpleGenerators (e.g. arithmetic_u32.rs:376-426)
  *   p2gpu_last_error       <- the `anyhow::Error` text the reference unwraps
  *   p2gpu_ifft_batch / p2gpu_lde_batch / p2gpu_commit_values
  *                          <- plonky2 PolynomialValues::ifft,
@@ -111,6 +114,17 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *public_
  * circuit's device; it is only read. */
 int p2gpu_prove_dev(p2gpu_circuit *c, const uint64_t *wires_dev, const uint64_t *public_inputs, uint32_t n_pi,
                     uint8_t *proof_out, size_t *proof_len, p2gpu_timings *opt_timings);
+/* Row-local witness generators on the GPU (the reference's SimpleGenerator
+ * impls: arithmetic_u32.rs:376-426, add_many_u32.rs:329-378, subtraction_u32.rs:298-343,
+ * range_check_u32.rs:198-220, comparison.rs:439-537 + the stock gates'): given a device wire
+ * matrix whose gate INPUT wires are set (i.e. after copy-constraint propagation), derive every
+ * other wire of each row in place. */
+int p2gpu_fill_witness(p2gpu_circuit *c, uint64_t *wires_dev);
+/* prove from the ROUTED columns only (host, [num_routed_wires][n]): the non-routed columns are
+ * all gate-internal, so they are filled on the GPU instead of crossing PCIe (80 of 234 columns). */
+int p2gpu_prove_routed(p2gpu_circuit *c, const uint64_t *routed, const uint64_t *public_inputs, uint32_t n_pi,
+                       uint8_t *proof_out, size_t *proof_len, p2gpu_timings *opt_timings);
+
 /* optional knobs: "pow_hint" (u64; UINT64_MAX = grind), "self_check" (0/1, default 1: evaluate the
  * verifier's plonk identity at zeta on the host before FRI and return P2GPU_E_UNSATISFIED when the
  * witness does not satisfy the circuit; 0 = emit the proof anyway like upstream), "profile" (0/1: time every

@@ -62,6 +62,10 @@ int orc_prove(const orc_circuit *c, const uint64_t *wires, const uint64_t *publi
               uint64_t pow_hint, uint8_t *proof_out, size_t *proof_len, orc_trace *trace);
 int orc_verify(const orc_circuit *c, const uint8_t *proof, size_t len, orc_trace *trace);
 
+/* row-local witness generators: fill every wire a gate's own generator derives
+ * from the gate's input wires; wires [num_wires][n] in place */
+int orc_fill_witness(const orc_circuit *c, uint64_t *wires);
+
 /* stage-level entry points for parity tests */
 void orc_ntt(uint64_t *a, unsigned lg, int inverse);
 void orc_coset_lde(const uint64_t *coeffs, unsigned d, unsigned rate_bits, uint64_t *out /* 2^(d+rate_bits), natural */);

@@ -56,6 +56,7 @@ def lib():
         L.orc_circuit_digest.restype = None
         L.orc_prove.argtypes = [vp, vp, vp, ctypes.c_uint32, ctypes.c_uint64, vp, ctypes.POINTER(sz), ctypes.POINTER(Trace)]
         L.orc_verify.argtypes = [vp, vp, sz, ctypes.POINTER(Trace)]
+        L.orc_fill_witness.argtypes = [vp, vp]
         L.orc_ntt.argtypes = [vp, ctypes.c_uint, ctypes.c_int]
         L.orc_ntt.restype = None
         L.orc_coset_lde.argtypes = [vp, ctypes.c_uint, ctypes.c_uint, vp]
@@ -130,6 +131,13 @@ class OracleCircuit:
         if rc != 0:
             raise RuntimeError(f"orc_prove failed: {rc}")
         return out[:plen.value].tobytes(), tr
+
+    def fill_witness(self, wires):
+        w = _u64(wires).copy()
+        rc = lib().orc_fill_witness(self._h, w.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"orc_fill_witness failed: {rc}")
+        return w
 
     def verify(self, proof):
         p = np.frombuffer(proof, dtype=np.uint8)

@@ -225,6 +225,30 @@ def test_full_size_proof_is_accepted(pkg, orc, gpu, mix):
     cd.close()
 
 
+@pytest.mark.parametrize("d,mix,npi", [(7, "arith", 0), (9, "ecdsa", 9), (12, "ecdsa", 0), (13, "sha", 4)])
+def test_fill_witness_matches_oracle(pkg, orc, gpu, d, mix, npi):
+    """N1: the gates' row-local generators on the GPU.  From the routed columns alone the filled
+    matrix equals the generator's full witness, and equals the oracle's fill word for word."""
+    import torch
+
+    out = pkg.make_circuit(d, mix, 23, num_public_inputs=npi)
+    blob, wires = out[0], out[1]
+    pis = out[2] if npi else ()
+    cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
+    part = wires.copy()
+    part[80:, :] = 0                       # drop every non-routed (gate-internal) column
+    part[3, :] ^= part[3, :] & 0           # (routed columns untouched)
+    dev = torch.from_numpy(part.view(np.int64)).cuda()
+    cd.fill_witness(dev)
+    got = dev.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, oc.fill_witness(part))
+    assert np.array_equal(got, wires)
+    # proving from the routed columns only gives the same proof as from the full matrix
+    full = cd.prove(wires, public_inputs=pis).to_bytes()
+    assert cd.prove_routed(wires[:80], public_inputs=pis).to_bytes() == full
+    cd.close()
+
+
 # ---- one proof sharded over two ranks (coset sharding, SURVEY 8(e)) -----------------------------
 def _shard_worker(rank, world, port, d, mix, npi, q):
     import os

@@ -137,3 +137,24 @@ def test_synth_selector_groups(pkg):
     degs = [int(g[9]) for g in gates]
     assert degs == sorted(degs)
     assert [tuple(int(x) for x in g[6:8]) for g in gates] == [(0, 5)] * 5 + [(5, 10)] * 5 + [(10, 12)] * 2
+
+
+@pytest.mark.parametrize("mix,npi", [("arith", 0), ("sha", 3), ("ecdsa", 9)])
+def test_fill_witness_row_local_generators(pkg, orc, mix, npi):
+    """the gates' own generators (e.g. arithmetic_u32.rs:376-426,
+    comparison.rs:439-537) are row-local; from the routed columns alone they rebuild every
+    gate-internal column of the witness the generator produced, and the result still proves."""
+    out = pkg.make_circuit(8, mix, 4, num_public_inputs=npi)
+    blob, wires = out[0], out[1]
+    pis = out[2] if npi else ()
+    oc = orc.OracleCircuit(blob)
+    assert np.array_equal(oc.fill_witness(wires), wires)  # idempotent on a complete witness
+    part = wires.copy()
+    part[80:, :] = 0
+    filled = oc.fill_witness(part)
+    assert np.array_equal(filled, wires)
+    assert oc.verify(oc.prove(filled, public_inputs=pis)[0])
+    # a wrong input propagates into the derived wires (and the proof is rejected: copy constraints)
+    bad = wires.copy()
+    bad[0, 10] = (int(bad[0, 10]) + 1) % P
+    assert not np.array_equal(oc.fill_witness(bad), wires)

@@ -267,9 +267,14 @@ extern "C" {
 // with p2synth_free.  wires_out is [num_wires][2^d] column-major.
 // num_pi > 0 adds what `build()` adds for public inputs: PoseidonGate rows hashing them (overwrite-mode
 // sponge, 8 per permutation) and the PublicInputGate row wired to the hash; pis_out receives the values.
-int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint32_t num_pi, uint8_t **blob_out, size_t *blob_len,
-                 uint64_t **wires_out, uint32_t *num_wires_out, uint64_t *pis_out) {
-  const uint32_t W = 234, R = 80, K = 2, QF = 8, RATE_BITS = 3, CAP_H = 4, POW_BITS = 16, QUERIES = 28;
+// num_wires: 234 = CircuitConfig::wide_ecc_config() (the translator's shape, mod.rs:69), 135 =
+// standard_recursion_config() (used by the reference's memory tests, test_memory_operations.rs:160,389);
+// the custom gates size themselves from it exactly as their `num_ops(config)` do.
+int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint32_t num_pi, uint32_t num_wires, uint8_t **blob_out,
+                 size_t *blob_len, uint64_t **wires_out, uint32_t *num_wires_out, uint64_t *pis_out) {
+  const uint32_t W = num_wires ? num_wires : 234;
+  const uint32_t R = 80, K = 2, QF = 8, RATE_BITS = 3, CAP_H = 4, POW_BITS = 16, QUERIES = 28;
+  if (W != 234 && W != 135) return -5;
   if (d < 5 || d > 24) return -1;
   size_t n = (size_t)1 << d;
   std::string m(mix ? mix : "arith");
@@ -289,10 +294,14 @@ int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint32_t num_pi, ui
     gates.push_back(mk(G_BASE_SUM, 4, 16, 0, "BaseSumGate { num_limbs: 16 } + Base: 4", 4, 17, 0, 0.10));
     gates.push_back(mk(G_RANDOM_ACCESS, 4, 4, 2,
                        "RandomAccessGate { bits: 4, num_copies: 4, num_extra_constants: 2" + ph + "<D=2>", 5, 26, 2, 0.05));
-    gates.push_back(mk(G_U32_ARITHMETIC, 6, 0, 0, "U32ArithmeticGate { num_ops: 6" + ph, 4, 216, 0, 0.20));
-    gates.push_back(mk(G_U32_ADD_MANY, 3, 9, 0, "U32AddManyGate { num_addends: 3, num_ops: 9" + ph, 4, 189, 0, 0.10));
-    gates.push_back(mk(G_U32_SUBTRACTION, 11, 0, 0, "U32SubtractionGate { num_ops: 11" + ph, 4, 209, 0, 0.10));
-    gates.push_back(mk(G_U32_RANGE_CHECK, 8, 0, 0, "U32RangeCheckGate { num_input_limbs: 8" + ph, 4, 136, 0, 0.10));
+    // arithmetic_u32.rs:39-42, add_many_u32.rs:43-48, subtraction_u32.rs:39-43: ops = min(wires / per-op wires, routed / per-op routed)
+    const uint32_t ua = std::min(W / 38, R / 6), am = std::min(W / 24, R / 6), us = std::min(W / 21, R / 5);
+    const uint32_t rcl = W >= 136 ? 8 : 7;  // U32RangeCheckGate{8} needs 136 wires
+    auto S = [](uint32_t v) { return std::to_string(v); };
+    gates.push_back(mk(G_U32_ARITHMETIC, ua, 0, 0, "U32ArithmeticGate { num_ops: " + S(ua) + ph, 4, ua * 36, 0, 0.20));
+    gates.push_back(mk(G_U32_ADD_MANY, 3, am, 0, "U32AddManyGate { num_addends: 3, num_ops: " + S(am) + ph, 4, am * 21, 0, 0.10));
+    gates.push_back(mk(G_U32_SUBTRACTION, us, 0, 0, "U32SubtractionGate { num_ops: " + S(us) + ph, 4, us * 19, 0, 0.10));
+    gates.push_back(mk(G_U32_RANGE_CHECK, rcl, 0, 0, "U32RangeCheckGate { num_input_limbs: " + S(rcl) + ph, 4, rcl * 17, 0, 0.10));
     gates.push_back(mk(G_COMPARISON, 32, 16, 0, "ComparisonGate { num_bits: 32, num_chunks: 16" + ph + "<D=2>", 4, 88, 0, 0.05));
   } else {
     return -2;

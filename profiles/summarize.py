@@ -60,6 +60,22 @@ def main():
     with open(os.path.join(here, f"{tag}_pmc_summary.json"), "w") as fo:
         json.dump({"note": "bytes = KiB * 1024; read side doubled (gfx950 FETCH_SIZE correction); separate --pmc passes",
                    "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline (scratch/prof.sh)", "kernels": out}, fo, indent=1)
+    # SQ counters (one more --pmc pass): where the waves' cycles go -- VALU issue vs waiting
+    sq_names = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES"]
+    sq = {}
+    for cn in sq_names:
+        for k, (avg, nl) in counter_avgs(os.path.join(src, "sq"), cn).items():
+            sq.setdefault(k, {"launches": nl})[cn] = avg
+    if sq:
+        for k, v in sq.items():
+            wc = v.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+            v["frac_valu_active"] = v.get("SQ_ACTIVE_INST_VALU", 0.0) / wc
+            v["frac_wait_memory_or_barrier"] = v.get("SQ_WAIT_ANY", 0.0) / wc
+            v["frac_wait_issue"] = v.get("SQ_WAIT_INST_ANY", 0.0) / wc
+        with open(os.path.join(here, f"{tag}_sq_summary.json"), "w") as fo:
+            json.dump({"note": "per-launch averages of SQ counters (quad-cycle units summed over waves); fractions are of SQ_WAVE_CYCLES",
+                       "kernels": sq}, fo, indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
         print(f"{k:32s} n={v['launches']:4d} read {v['hbm_read_bytes_per_launch']/1e6:10.1f} MB  write {v['hbm_write_bytes_per_launch']/1e6:10.1f} MB")
 

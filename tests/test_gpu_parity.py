@@ -116,6 +116,20 @@ def test_public_inputs_proof_bytes_match_oracle(pkg, orc, gpu, d, mix, npi):
     cd.close()
 
 
+@pytest.mark.parametrize("d,mix,npi", [(6, "ecdsa", 0), (11, "ecdsa", 5), (13, "sha", 0)])
+def test_standard_recursion_config_proofs(pkg, orc, gpu, d, mix, npi):
+    """135-wire shape (standard_recursion_config): different column counts, gate op counts and
+    Keccak block tail than the 234-wire shape."""
+    out = pkg.make_circuit(d, mix, 19, num_public_inputs=npi, num_wires=135)
+    blob, wires = out[0], out[1]
+    pis = out[2] if npi else ()
+    cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
+    expect, _ = oc.prove(wires, public_inputs=pis)
+    assert cd.prove(wires, public_inputs=pis).to_bytes() == expect
+    assert cd.prove_routed(wires[:80], public_inputs=pis).to_bytes() == expect
+    cd.close()
+
+
 def test_golden_proof_digests_on_gpu(pkg, gpu):
     """Committed regression vectors (tests/golden/proof_digests.json) without running the oracle."""
     with open(os.path.join(GOLDEN, "proof_digests.json")) as f:

@@ -158,3 +158,20 @@ def test_fill_witness_row_local_generators(pkg, orc, mix, npi):
     bad = wires.copy()
     bad[0, 10] = (int(bad[0, 10]) + 1) % P
     assert not np.array_equal(oc.fill_witness(bad), wires)
+
+
+@pytest.mark.parametrize("mix,npi", [("ecdsa", 0), ("sha", 2)])
+def test_standard_recursion_config_shape(pkg, orc, mix, npi):
+    """135-wire circuits (standard_recursion_config, as in the reference's memory tests
+    test_memory_operations.rs:160,389): the custom gates shrink to 3 / 5 / 6 ops, a wires leaf is
+    135 * 8 bytes = 7 full Keccak blocks + 16 words (both padding bits land in the last rate word)."""
+    out = pkg.make_circuit(7, mix, 6, num_public_inputs=npi, num_wires=135)
+    blob, wires = out[0], out[1]
+    pis = out[2] if npi else ()
+    assert wires.shape[0] == 135 and int(blob[:256].view(np.uint32)[3]) == 135
+    oc = orc.OracleCircuit(blob)
+    proof, _ = oc.prove(wires, public_inputs=pis)
+    assert oc.verify(proof)
+    bad = wires.copy()
+    bad[5, 9] = (int(bad[5, 9]) + 1) % P
+    assert not oc.verify(oc.prove(bad, public_inputs=pis)[0])

@@ -1,0 +1,83 @@
+/*
+ * p2gpu-prove -- stand-alone caller of the C ABI (include/p2gpu.h), plain C, no Python:
+ *
+ *     p2gpu-prove <circuit.blob> <wires.bin> <proof.bin> [public_inputs.bin] [--routed]
+ *
+ * The counterpart of `plonky2-backend prove -b <acir> -w <witness> -o <proof>`
+ * (plonky2-backend/src/argument_parsing.rs:36-41 -> actions/prove_action.rs:27-43) below the
+ * translation layer: the circuit blob is what the Rust side exports once per circuit and
+ * wires.bin is the dense witness matrix [num_wires][n] of little-endian u64 (with --routed only
+ * the [num_routed_wires][n] routed columns; the rest is derived on the GPU).  Writes the
+ * uncompressed ProofWithPublicInputs bytes.  Exit code 0 = ok, 1 = usage/IO, 2 = library error.
+ */
+#include "../../include/p2gpu.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static void *slurp(const char *path, size_t *len) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return NULL;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  rewind(f);
+  void *buf = malloc(n > 0 ? (size_t)n : 1);
+  if (buf && fread(buf, 1, (size_t)n, f) != (size_t)n) {
+    free(buf);
+    buf = NULL;
+  }
+  fclose(f);
+  *len = (size_t)n;
+  return buf;
+}
+
+int main(int argc, char **argv) {
+  int routed = 0, npos = 0;
+  const char *pos[4] = {0, 0, 0, 0};
+  for (int i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "--routed")) routed = 1;
+    else if (npos < 4) pos[npos++] = argv[i];
+  }
+  if (npos < 3) {
+    fprintf(stderr, "usage: %s <circuit.blob> <wires.bin> <proof.bin> [public_inputs.bin] [--routed]\n", argv[0]);
+    return 1;
+  }
+  size_t blob_len, wires_len, pi_len = 0;
+  uint8_t *blob = slurp(pos[0], &blob_len);
+  uint64_t *wires = slurp(pos[1], &wires_len);
+  uint64_t *pis = pos[3] ? slurp(pos[3], &pi_len) : NULL;
+  if (!blob || !wires || (pos[3] && !pis)) {
+    fprintf(stderr, "cannot read inputs\n");
+    return 1;
+  }
+  p2gpu_circuit *c = NULL;
+  int rc = p2gpu_circuit_create(blob, blob_len, &c);
+  if (rc) {
+    fprintf(stderr, "p2gpu_circuit_create: %d: %s\n", rc, p2gpu_last_error());
+    return 2;
+  }
+  size_t cap = p2gpu_proof_size_bound(c), len = cap;
+  uint8_t *proof = malloc(cap);
+  p2gpu_timings t;
+  rc = routed ? p2gpu_prove_routed(c, wires, pis, (uint32_t)(pi_len / 8), proof, &len, &t)
+              : p2gpu_prove(c, wires, pis, (uint32_t)(pi_len / 8), proof, &len, &t);
+  if (rc) {
+    fprintf(stderr, "p2gpu_prove: %d: %s\n", rc, p2gpu_last_error());
+    p2gpu_circuit_destroy(c);
+    return 2;
+  }
+  FILE *f = fopen(pos[2], "wb");
+  if (!f || fwrite(proof, 1, len, f) != len) {
+    fprintf(stderr, "cannot write %s\n", pos[2]);
+    return 1;
+  }
+  fclose(f);
+  fprintf(stderr, "proof: %zu bytes; wires %.2f ms, zs %.2f ms, quotient %.2f ms, openings %.2f ms, fri %.2f ms, h2d %.2f ms\n", len,
+          t.wires_commit_ms, t.zs_commit_ms, t.quotient_ms, t.openings_ms, t.fri_ms, t.h2d_ms);
+  p2gpu_circuit_destroy(c);
+  free(proof);
+  free(blob);
+  free(wires);
+  free(pis);
+  return 0;
+}

@@ -197,7 +197,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
-            "dtype": "u64 (Goldilocks field, p = 2^64 - 2^32 + 1)",
+            "dtype": "u64",
             "data": "synthetic",
             "config": {
                 "workload": f"synth(d={d},{mix}): {1 << d} gates -> 2^{d + 3} LDE rows, 234 wires / 80 routed, "

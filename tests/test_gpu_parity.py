@@ -263,6 +263,32 @@ def test_fill_witness_matches_oracle(pkg, orc, gpu, d, mix, npi):
     cd.close()
 
 
+def test_standalone_c_caller(pkg, orc, gpu, tmp_path):
+    """`p2gpu-prove` is a plain-C program on the C ABI (no Python/torch in the process): same bytes."""
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = os.path.join(ROOT, "acvm-backend-plonky2_amd", "p2gpu-prove")
+    assert os.path.exists(exe)
+    blob, wires, pis = pkg.make_circuit(9, "ecdsa", 29, num_public_inputs=3)
+    (tmp_path / "c.blob").write_bytes(blob.tobytes())
+    (tmp_path / "w.bin").write_bytes(wires.tobytes())
+    (tmp_path / "r.bin").write_bytes(np.ascontiguousarray(wires[:80]).tobytes())
+    (tmp_path / "pi.bin").write_bytes(pis.tobytes())
+    expect, _ = orc.OracleCircuit(blob).prove(wires, public_inputs=pis)
+    for args, out in ((["w.bin"], "p1.bin"), (["r.bin", "--routed"], "p2.bin")):
+        cmd = [exe, str(tmp_path / "c.blob"), str(tmp_path / args[0]), str(tmp_path / out), str(tmp_path / "pi.bin")] + args[1:]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert (tmp_path / out).read_bytes() == expect
+    # a broken blob is reported through the error code + message, not a crash
+    (tmp_path / "bad.blob").write_bytes(b"\0" * 300)
+    r = subprocess.run([exe, str(tmp_path / "bad.blob"), str(tmp_path / "w.bin"), str(tmp_path / "p3.bin")],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "p2gpu_circuit_create" in r.stderr
+
+
 # ---- one proof sharded over two ranks (coset sharding, SURVEY 8(e)) -----------------------------
 def _shard_worker(rank, world, port, d, mix, npi, q):
     import os

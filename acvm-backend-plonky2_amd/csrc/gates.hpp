@@ -26,7 +26,7 @@ enum {
 struct GateDesc {
   uint32_t kind, p[4];
   uint32_t sel_index, group_start, group_end;
-  uint32_t num_constraints, degree, num_constants, pad;
+  uint32_t num_constraints, degree, num_constants, pad;  // pad: evaluation group (quotient kernel, heavy mixes)
 };
 
 struct BaseOps {

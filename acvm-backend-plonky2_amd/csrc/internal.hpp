@@ -89,6 +89,7 @@ struct QuotArgs {
   const GateDesc *gates; // device copy
   gl_t *out;             // [K][cosets][n]
   uint32_t tw_shift, d, rate_bits, W, R, NC, num_selectors, K, QF, nchunks, PP, num_gates, nterms, has_poseidon;
+  uint32_t gate_groups;  // 1, or 4: gates split over the four waves of a 64-row block (GateDesc.pad = group)
   uint32_t coset_first, coset_stride, ncosets;  // sharding: grid.y = local coset z, global r = first + z * stride;
                                                 // cs_lde/qconst are indexed by r, wires/zp/out by z
   gl_t betas[MAX_CHALLENGES], gammas[MAX_CHALLENGES];

@@ -173,9 +173,15 @@ struct Consumer {
   }
 };
 
-// grid: x = k blocks, y = coset
-template <bool POSEIDON>
+// grid: x = k blocks, y = coset.  G = 1: one lane per LDE row does everything (block 256 x 1).
+// G = 4 (heavy gate mixes): block 64 x 4 -- the four waves of a block share one 64-row tile and
+// each evaluates its share of the gates (GateDesc.pad = group; group 0 also does the permutation
+// argument), so the tile's wires are pulled from HBM once per block instead of once per gate
+// (reuse distance ~120 KB per wave defeats L2 otherwise); partial sums meet in LDS.
+template <bool POSEIDON, int G>
 __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
+  __shared__ gl_t red[2][G > 1 ? G : 1][G > 1 ? 64 : 1];
+  const uint32_t grp = G > 1 ? threadIdx.y : 0;
   const uint32_t n = 1u << a.d;
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t z = blockIdx.y;                             // local coset
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
   out.ap0 = a.apow;
   out.ap1 = a.apow + a.nterms;
   out.t = 0;
+  if (grp == 0) {
   // L_0(x) (Z_c(x) - 1),  L_0(x) = Z_H(x) / (n (x - 1))
   const gl_t l0 = gl_mul(gl_mul(a.qconst[8 + r], a.n_inv), gl_inv(gl_sub(x, 1)));
   for (uint32_t c = 0; c < a.K; c++) out.emit(gl_mul(l0, gl_sub(zl[(size_t)c * n + k], 1)));
@@ -224,14 +231,16 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
     }
     out.t = t_base + a.K * a.nchunks;
   }
+  }
   // gate constraints: every gate on every row, masked by its selector filter
-  const uint32_t t_gates = out.t;
+  const uint32_t t_gates = a.K + a.K * a.nchunks;
   gl_t tot0 = out.acc0, tot1 = out.acc1;
   auto W = [&](uint32_t c) { return wl[(size_t)c * n]; };
   auto LC = [&](uint32_t i) { return cs[(size_t)(a.num_selectors + i) * n]; };
   for (uint32_t gi = 0; gi < a.num_gates; gi++) {
     const GateDesc g = a.gates[gi];
     if (g.num_constraints == 0) continue;
+    if (G > 1 && g.pad != grp) continue;
     const gl_t s = cs[(size_t)g.sel_index * n];
     const gl_t f = gate_filter<BaseOps>(g, gi, a.num_selectors, s);
     out.acc0 = 0;
@@ -241,6 +250,16 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
     tot0 = gl_add(tot0, gl_mul(f, out.acc0));
     tot1 = gl_add(tot1, gl_mul(f, out.acc1));
   }
+  if constexpr (G > 1) {
+    red[0][grp][threadIdx.x] = tot0;
+    red[1][grp][threadIdx.x] = tot1;
+    __syncthreads();
+    if (grp != 0) return;
+    for (int q = 1; q < G; q++) {
+      tot0 = gl_add(tot0, red[0][q][threadIdx.x]);
+      tot1 = gl_add(tot1, red[1][q][threadIdx.x]);
+    }
+  }
   const gl_t zi = a.qconst[16 + r];
   a.out[((size_t)0 * a.ncosets + z) * n + k] = gl_mul(tot0, zi);
   if (a.K > 1) a.out[((size_t)1 * a.ncosets + z) * n + k] = gl_mul(tot1, zi);
@@ -249,11 +268,17 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
 void quotient_eval(hipStream_t st, const QuotArgs &a) {
   const uint32_t n = 1u << a.d;
   const uint32_t threads = n >= 256 ? 256 : 64;
-  ProfScope ps(a.has_poseidon ? "quotient_kernel<true>" : "quotient_kernel<false>", 8.0 * (double)n * a.ncosets * (a.NC + a.R + a.W + a.K * (1 + a.PP) + 2.0 * a.K));
-  if (a.has_poseidon)
-    hipLaunchKernelGGL(quotient_kernel<true>, dim3((n + threads - 1) / threads, a.ncosets), dim3(threads), 0, st, a);
-  else
-    hipLaunchKernelGGL(quotient_kernel<false>, dim3((n + threads - 1) / threads, a.ncosets), dim3(threads), 0, st, a);
+  ProfScope ps(a.has_poseidon ? "quotient_kernel<true>" : "quotient_kernel<false>",
+               8.0 * (double)n * a.ncosets * (a.NC + a.R + a.W + a.K * (1 + a.PP) + 2.0 * a.K));
+  if (a.gate_groups == 4 && n >= 64) {
+    dim3 grid(n / 64, a.ncosets), block(64, 4);
+    if (a.has_poseidon) hipLaunchKernelGGL((quotient_kernel<true, 4>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((quotient_kernel<false, 4>), grid, block, 0, st, a);
+  } else {
+    dim3 grid((n + threads - 1) / threads, a.ncosets), block(threads);
+    if (a.has_poseidon) hipLaunchKernelGGL((quotient_kernel<true, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((quotient_kernel<false, 1>), grid, block, 0, st, a);
+  }
 }
 
 // in [K][C][n]: coefficients (bit-reversed storage) of the per-coset interpolants

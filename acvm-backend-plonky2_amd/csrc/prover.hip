@@ -172,6 +172,7 @@ struct p2gpu_circuit {
   std::vector<GateDesc> gates;
   std::vector<gl_t> k_is;
   uint32_t nterms = 0, max_gate_constraints = 0;
+  uint32_t gate_groups = 1;  // quotient kernel: 1, or 4 when the gate set is heavy
   int device = 0;
   hipStream_t stream = nullptr;
   // tables
@@ -541,6 +542,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     q.coset_first = c->wires.cm.first;
     q.coset_stride = c->wires.cm.stride;
     q.ncosets = c->wires.ncl;
+    q.gate_groups = c->gate_groups;
     q.has_poseidon = 0;
     for (auto &g : c->gates)
       if (g.kind == G_POSEIDON) q.has_poseidon = 1;
@@ -1040,6 +1042,28 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     c->gates.push_back(G);
   }
   c->nterms = c->K + c->K * c->nchunks + c->max_gate_constraints;
+  {
+    // heavy gate mixes: split the gates over 4 waves that share a row tile (plonk.hip); greedy
+    // balance by an estimate of modmuls per row, group 0 starts with the permutation argument
+    auto cost = [](const GateDesc &g) { return g.kind == G_POSEIDON ? 6000u : 4u * g.num_constraints + 8u; };
+    const uint32_t perm_cost = 8u * c->R + 100u;
+    uint32_t total = 0;
+    for (auto &g : c->gates) total += cost(g);
+    const char *env = getenv("P2GPU_GATE_GROUPS");
+    c->gate_groups = env ? (uint32_t)atoi(env) : (total > 2 * perm_cost ? 4u : 1u);
+    if (c->gate_groups != 4) c->gate_groups = 1;
+    uint32_t load[4] = {perm_cost, 0, 0, 0};
+    std::vector<uint32_t> order(c->gates.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost(c->gates[x]) > cost(c->gates[y]); });
+    for (uint32_t gi : order) {
+      uint32_t best = 0;
+      for (uint32_t q = 1; q < 4; q++)
+        if (load[q] < load[best]) best = q;
+      c->gates[gi].pad = c->gate_groups == 4 ? best : 0;
+      load[best] += cost(c->gates[gi]);
+    }
+  }
   const uint8_t *cap_in = nullptr;
   if (c->flags & 2) {
     cap_in = blob + off;

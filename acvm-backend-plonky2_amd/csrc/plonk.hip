@@ -268,9 +268,12 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
 void quotient_eval(hipStream_t st, const QuotArgs &a) {
   const uint32_t n = 1u << a.d;
   const uint32_t threads = n >= 256 ? 256 : 64;
-  ProfScope ps(a.has_poseidon ? "quotient_kernel<true>" : "quotient_kernel<false>",
-               8.0 * (double)n * a.ncosets * (a.NC + a.R + a.W + a.K * (1 + a.PP) + 2.0 * a.K));
-  if (a.gate_groups == 4 && n >= 64) {
+  const bool split = a.gate_groups == 4 && n >= 64;
+  // same spelling as rocprofv3's demangled names
+  const char *name = split ? (a.has_poseidon ? "quotient_kernel<true, 4>" : "quotient_kernel<false, 4>")
+                           : (a.has_poseidon ? "quotient_kernel<true, 1>" : "quotient_kernel<false, 1>");
+  ProfScope ps(name, 8.0 * (double)n * a.ncosets * (a.NC + a.R + a.W + a.K * (1 + a.PP) + 2.0 * a.K));
+  if (split) {
     dim3 grid(n / 64, a.ncosets), block(64, 4);
     if (a.has_poseidon) hipLaunchKernelGGL((quotient_kernel<true, 4>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((quotient_kernel<false, 4>), grid, block, 0, st, a);

@@ -43,10 +43,11 @@ struct CosetMap {
 };
 NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse);
 void ntt_plan_destroy(NttPlan *p);
-// src [cols][n] (or [cosets][cols][n] when src_per_coset), dst [cosets][cols][n].
+// src [cols][n] (or [cosets][cols][n] when src_per_coset), dst [cosets][cols][n]; stride_cols != 0: the
+// launch covers `cols` columns of a batch that has stride_cols columns per coset (chunked pipelines).
 // scale (DIT only): [cosets][n] multiplied into the input; post: multiplied into the output.
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
-               const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm = CosetMap());
+               const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm = CosetMap(), uint32_t stride_cols = 0);
 void fill_powers(hipStream_t st, gl_t *out, gl_t root, uint32_t count);
 void fill_coset_scale(hipStream_t st, gl_t *out, gl_t shift, gl_t wN, uint32_t d, uint32_t cosets, gl_t mult);
 void bitrev_cols(hipStream_t st, const gl_t *in, gl_t *out, uint32_t d, uint32_t cols);

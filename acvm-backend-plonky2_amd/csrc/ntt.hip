@@ -365,7 +365,7 @@ void ntt_plan_destroy(NttPlan *p) {
 }
 
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
-               const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm) {
+               const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_cols) {
   if (cols == 0) return;
   const uint32_t d = plan->d;
   const size_t np = plan->passes.size();
@@ -379,7 +379,7 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     A.post = (i == np - 1) ? post : 1;
     A.d = d;
     A.s = ps.s; A.a = ps.a; A.tb = ps.tb;
-    A.cols = cols;
+    A.cols = stride_cols ? stride_cols : cols;  // column stride between cosets (a launch may cover a column chunk)
     A.src_single = (i == 0 && !src_per_coset) ? 1 : 0;
     A.coset_first = cm.first;
     A.coset_stride = cm.stride;

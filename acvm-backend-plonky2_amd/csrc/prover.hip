@@ -175,6 +175,9 @@ struct p2gpu_circuit {
   uint32_t gate_groups = 1;  // quotient kernel: 1, or 4 when the gate set is heavy
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // H2D of the witness, overlapped with the transforms of earlier columns
+  std::vector<hipEvent_t> copy_events;
+  bool wires_ntt_done = false;        // set by p2gpu_prove: coefficients + LDE of the wires already enqueued
   // tables
   DBuf<gl_t> tw_fwd, tw_inv, scale, inv_scale, d_kis, d_sigmas, fri_scale, qconst;
   DBuf<GateDesc> d_gates;
@@ -340,7 +343,14 @@ int batch_commit_from_coeffs(p2gpu_circuit *c, Batch &b) {
   TRACE(c, "  lde + leaf hash");
   return tree_build(c, b, c->n);
 }
+// hash + tree of a batch whose LDE is already in place
+int batch_commit_from_lde(p2gpu_circuit *c, Batch &b) {
+  hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p);
+  TRACE(c, "  leaf hash");
+  return tree_build(c, b, c->n);
+}
 int batch_commit_from_values(p2gpu_circuit *c, Batch &b, const gl_t *vals_dev) {
+  if (&b == &c->wires && c->wires_ntt_done) return batch_commit_from_lde(c, b);
   {
     gl_t ninv = gl_inv((gl_t)c->n);
     ntt_batch(c->stream, c->plan_inv, vals_dev, b.coeffs.p, b.cols, 1, nullptr, ninv, false);
@@ -892,6 +902,8 @@ void circuit_release(p2gpu_circuit *c) {
   c->plan_inv = c->plan_fwd = nullptr;
   c->fri_plans.clear();
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
+  for (auto e : c->copy_events) (void)hipEventDestroy(e);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -1097,6 +1109,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   poseidon_round_constants_host(c->poseidon_rc);
   if (poseidon_upload_constants()) return fail(P2GPU_E_DEVICE, "uploading Poseidon constants failed");
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+  CK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
   hipStream_t st = c->stream;
   const uint32_t d = c->d, K = c->K, C = c->C;
   const uint32_t ncs = c->NC + c->R, nzp = K * (1 + c->PP), nq = K * c->QF;
@@ -1393,11 +1406,35 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
                 size_t *proof_len, p2gpu_timings *tm) {
   if (!c || !wires || !proof_out || !proof_len) return P2GPU_E_ARG;
   HIP_TRY(hipSetDevice(c->device));
-  double t0 = now_ms();
-  HIP_TRY(hipMemcpyAsync(c->wires_vals.p, wires, 8 * (size_t)c->W * c->n, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  double h2d = now_ms() - t0;
-  return prove_impl(c, c->wires_vals.p, pis, n_pi, proof_out, proof_len, tm, h2d);
+  // The witness crosses PCIe in column chunks on a copy stream; the inverse transform and the
+  // LDE of a chunk run while the next chunk is still in flight (values -> coefficients -> LDE are
+  // per-column; only the leaf hash needs every column).
+  const double t0 = now_ms();
+  const uint32_t W = c->W, chunk = 26;
+  const size_t n = c->n;
+  const gl_t ninv = gl_inv((gl_t)n);
+  Batch &b = c->wires;
+  uint32_t ci = 0;
+  for (uint32_t col0 = 0; col0 < W; col0 += chunk, ci++) {
+    const uint32_t nc = std::min(chunk, W - col0);
+    if (ci >= c->copy_events.size()) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      c->copy_events.push_back(e);
+    }
+    gl_t *vals = c->wires_vals.p + (size_t)col0 * n;
+    HIP_TRY(hipMemcpyAsync(vals, wires + (size_t)col0 * n, 8 * (size_t)nc * n, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(hipEventRecord(c->copy_events[ci], c->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->copy_events[ci], 0));
+    ntt_batch(c->stream, c->plan_inv, vals, b.coeffs.p + (size_t)col0 * n, nc, 1, nullptr, ninv, false);
+    ntt_batch(c->stream, c->plan_fwd, b.coeffs.p + (size_t)col0 * n, b.lde.p + (size_t)col0 * n, nc, b.ncl, c->scale.p, 1,
+              false, b.cm, W);
+  }
+  const double h2d = now_ms() - t0;  // host time spent feeding PCIe (the transforms overlap with it)
+  c->wires_ntt_done = true;
+  int rc = prove_impl(c, c->wires_vals.p, pis, n_pi, proof_out, proof_len, tm, h2d);
+  c->wires_ntt_done = false;
+  return rc;
 }
 
 // ---- stage-level operators (host buffers) ----

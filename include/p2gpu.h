@@ -127,8 +127,9 @@ int p2gpu_prove_routed(p2gpu_circuit *c, const uint64_t *routed, const uint64_t 
 
 /* optional knobs: "pow_hint" (u64; UINT64_MAX = grind), "self_check" (0/1, default 1: evaluate the
  * verifier's plonk identity at zeta on the host before FRI and return P2GPU_E_UNSATISFIED when the
- * witness does not satisfy the circuit; 0 = emit the proof anyway like upstream), "profile" (0/1: time every
- * kernel launch with HIP events on the launch stream; resets the statistics) */
+ * witness does not satisfy the circuit; 0 = emit the proof anyway like upstream), "profile" (0 / 1 / 2: time kernel
+ * launches with HIP events on the launch stream -- 1 = the launches that move >= 32 MB, 2 = every launch;
+ * resets the statistics) */
 int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value);
 /* statistics accumulated while "profile" = 1, one entry per kernel symbol:
  * names[64*i] (NUL-terminated), total milliseconds, total algorithmic bytes,

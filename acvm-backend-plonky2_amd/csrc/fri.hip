@@ -73,17 +73,48 @@ void eval_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d,
   hipLaunchKernelGGL(eval_columns_kernel, dim3(parts, cols), dim3(256), 0, st, coeffs, d, pw, parts, partial);
 }
 
+// block = 64 positions x 4 column groups: group g sums the columns j = g mod 4 (8 loads in flight
+// per lane), the four partial sums meet in LDS.  (One lane per position alone would be 2 waves per
+// SIMD at n = 2^17, each walking 354 columns with a single load in flight.)
 __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restrict__ coeffs, uint32_t cols, uint32_t d,
                                                              const gl_t *__restrict__ apow, uint32_t j0,
                                                              gl_t *__restrict__ acc, int accumulate) {
+  __shared__ gl_t red[2][4][64];
   const uint32_t n = 1u << d;
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  gl_t a0 = accumulate ? acc[p] : 0, a1 = accumulate ? acc[(size_t)n + p] : 0;
-  for (uint32_t j = 0; j < cols; j++) {
-    gl_t v = coeffs[(size_t)j * n + p];
-    a0 = gl_add(a0, gl_mul(v, apow[2 * (j0 + j)]));
-    a1 = gl_add(a1, gl_mul(v, apow[2 * (j0 + j) + 1]));
+  const uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t g = threadIdx.y;
+  const bool live = p < n;
+  gl_t a0 = 0, a1 = 0;
+  if (live) {
+    uint32_t j = g;
+#pragma unroll 1
+    for (; j + 28 < cols; j += 32) {
+      gl_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = coeffs[(size_t)(j + 4 * u) * n + p];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        a0 = gl_add(a0, gl_mul(v[u], apow[2 * (j0 + j + 4 * u)]));
+        a1 = gl_add(a1, gl_mul(v[u], apow[2 * (j0 + j + 4 * u) + 1]));
+      }
+    }
+    for (; j < cols; j += 4) {
+      const gl_t v = coeffs[(size_t)j * n + p];
+      a0 = gl_add(a0, gl_mul(v, apow[2 * (j0 + j)]));
+      a1 = gl_add(a1, gl_mul(v, apow[2 * (j0 + j) + 1]));
+    }
+  }
+  red[0][g][threadIdx.x] = a0;
+  red[1][g][threadIdx.x] = a1;
+  __syncthreads();
+  if (g != 0 || !live) return;
+  for (int q = 1; q < 4; q++) {
+    a0 = gl_add(a0, red[0][q][threadIdx.x]);
+    a1 = gl_add(a1, red[1][q][threadIdx.x]);
+  }
+  if (accumulate) {
+    a0 = gl_add(a0, acc[p]);
+    a1 = gl_add(a1, acc[(size_t)n + p]);
   }
   acc[p] = a0;
   acc[(size_t)n + p] = a1;
@@ -91,10 +122,9 @@ __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restr
 void reduce_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *apow, uint32_t j0,
                     gl_t *acc, bool accumulate) {
   uint32_t n = 1u << d;
-  uint32_t threads = n >= 256 ? 256 : 64;
   ProfScope ps("reduce_columns_kernel", 8.0 * (cols + 4.0) * (double)n);
-  hipLaunchKernelGGL(reduce_columns_kernel, dim3((n + threads - 1) / threads), dim3(threads), 0, st, coeffs, cols, d,
-                     apow, j0, acc, accumulate ? 1 : 0);
+  hipLaunchKernelGGL(reduce_columns_kernel, dim3((n + 63) / 64), dim3(64, 4), 0, st, coeffs, cols, d, apow, j0, acc,
+                     accumulate ? 1 : 0);
 }
 
 __global__ __launch_bounds__(256) void fri_quotient_values_kernel(const gl_t *F0, const gl_t *F1, uint32_t d,

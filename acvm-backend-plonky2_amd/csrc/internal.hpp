@@ -8,7 +8,7 @@
 
 namespace p2 {
 
-constexpr int MAX_GATES = 32;
+constexpr int MAX_GATES = 64;
 constexpr int MAX_CHALLENGES = 2;
 constexpr int MAX_ROUTED = 128;
 

@@ -23,11 +23,23 @@ __device__ __forceinline__ dig_t sponge_hash(uint32_t nwords, F get) {
 #pragma unroll
   for (int i = 0; i < 25; i++) st[i] = 0;
   uint32_t off = 0;
+  // software pipeline: the 17 words of block b+1 are requested before Keccak-f runs on block b,
+  // so the loads (one 512 B wave access per column) fly under ~4300 VALU instructions
+  uint64_t nxt[17];
+  const bool first_full = nwords >= 17;
+  if (first_full) {
+#pragma unroll
+    for (int w = 0; w < 17; w++) nxt[w] = get(w);
+  }
   while (nwords - off >= 17) {
 #pragma unroll
-    for (int w = 0; w < 17; w++) st[w] ^= get(off + w);
-    keccak_f1600(st);
+    for (int w = 0; w < 17; w++) st[w] ^= nxt[w];
     off += 17;
+    if (nwords - off >= 17) {
+#pragma unroll
+      for (int w = 0; w < 17; w++) nxt[w] = get(off + w);
+    }
+    keccak_f1600(st);
   }
   const uint32_t rem = nwords - off;
 #pragma unroll

@@ -1,0 +1,170 @@
+// circuit.hpp -- host-side types shared by the prover pipeline (prover.hip) and the verifier
+// (verify.hip): the Fiat-Shamir transcript, the committed-batch bookkeeping and the circuit handle
+// behind the opaque `p2gpu_circuit` of include/p2gpu.h.
+#pragma once
+#include "internal.hpp"
+#include "poseidon.hpp"
+#include "../../include/p2gpu.h"
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace p2 {
+
+// thread-local message behind p2gpu_last_error()
+void set_err(const char *fmt, ...);
+
+// ---- host transcript (iop/challenger.rs, Challenger<F, KeccakHash<25>>) ----
+struct Challenger {
+  gl_t state[12];
+  gl_t in[8];
+  int n_in = 0;
+  gl_t out[8];
+  int n_out = 0;
+  Challenger() { memset(state, 0, sizeof state); }
+  void duplex() {
+    for (int i = 0; i < n_in; i++) state[i] = in[i];
+    n_in = 0;
+    keccak_permutation12(state);
+    for (int i = 0; i < 8; i++) out[i] = state[i];
+    n_out = 8;
+  }
+  void observe(gl_t e) {
+    n_out = 0;
+    in[n_in++] = e;
+    if (n_in == 8) duplex();
+  }
+  void observe_digest(const dig_t &d) {
+    gl_t e[4];
+    dig_to_elems(d, e);
+    for (int i = 0; i < 4; i++) observe(e[i]);
+  }
+  void observe_cap(const std::vector<dig_t> &cap) {
+    for (auto &d : cap) observe_digest(d);
+  }
+  void observe_ext(ext_t e) {
+    observe(e.c0);
+    observe(e.c1);
+  }
+  gl_t get() {
+    if (n_in != 0 || n_out == 0) duplex();
+    return out[--n_out];
+  }
+  ext_t get_ext() {
+    gl_t a = get();
+    gl_t b = get();
+    return ext_make(a, b);
+  }
+};
+
+inline dig_t host_hash_no_pad(const std::vector<gl_t> &v) {
+  uint64_t h[4];
+  keccak256_words(v.data(), v.size(), h);
+  return dig_from_state(h);
+}
+
+template <class T>
+struct DBuf {
+  T *p = nullptr;
+  size_t count = 0;
+  hipError_t alloc(size_t n) {
+    count = n;
+    if (n == 0) return hipSuccess;
+    return hipMalloc((void **)&p, n * sizeof(T));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  }
+};
+
+// one committed polynomial batch (plonky2 PolynomialBatch), GPU layout
+struct Batch {
+  uint32_t cols = 0, d = 0;
+  uint32_t ncl = 0;   // cosets stored locally (all 2^rate_bits, or this rank's share when sharded)
+  CosetMap cm;        // local coset z <-> global coset cm.first + z * cm.stride
+  DBuf<gl_t> coeffs;  // [cols][n], bit-reversed positions
+  DBuf<gl_t> lde;     // [C][cols][n]
+  DBuf<dig_t> dig;    // all tree levels, level l at level_off[l], layout [C][n >> l]
+  std::vector<size_t> level_off;
+  std::vector<dig_t> cap;  // plonky2 order
+  void release() {
+    coeffs.release();
+    lde.release();
+    dig.release();
+  }
+};
+
+struct KernelStat {
+  double ms = 0, bytes = 0;
+  uint64_t launches = 0;
+};
+struct PendingEv {
+  const char *name;
+  double bytes;
+  hipEvent_t a, b;
+};
+
+
+// everything behind the opaque handle
+struct CircuitState {
+  // parameters
+  uint32_t d, W, R, NC, num_selectors, K, QF, rate_bits, cap_h, pow_bits, num_queries, n_steps, arity[8];
+  uint32_t num_gates, num_pi, flags, PP, nchunks;
+  size_t n, N;
+  uint32_t C;  // cosets = 2^rate_bits
+  std::vector<GateDesc> gates;
+  std::vector<gl_t> k_is;
+  uint32_t nterms = 0, max_gate_constraints = 0;
+  uint32_t gate_groups = 1;  // quotient kernel: 1, or 4 when the gate set is heavy
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // H2D of the witness, overlapped with the transforms of earlier columns
+  std::vector<hipEvent_t> copy_events;
+  bool wires_ntt_done = false;        // set by p2gpu_prove: coefficients + LDE of the wires already enqueued
+  // tables
+  DBuf<gl_t> tw_fwd, tw_inv, scale, inv_scale, d_kis, d_sigmas, fri_scale, qconst;
+  DBuf<GateDesc> d_gates;
+  DBuf<uint8_t> d_row_gate;   // [n] gate index of every row (from the selector columns)
+  DBuf<gl_t> d_gconsts, d_prc; // gate-constant columns [NC - num_selectors][n]; Poseidon round constants
+  NttPlan *plan_inv = nullptr, *plan_fwd = nullptr;  // size n: values->coeffs (DIF, w^-1), coeffs->values (DIT)
+  std::vector<NttPlan *> fri_plans;                   // DIT plans of the FRI step sizes
+  // oracles
+  Batch cs, wires, zp, quot;
+  dig_t circuit_digest;
+  gl_t poseidon_rc[360];
+  // work buffers
+  DBuf<gl_t> wires_vals, zp_vals, cp, rowprod, scan_tmp, apow, qvals, qtmp, pw, partial, ext_apow, f01, f01v, fv;
+  std::vector<DBuf<gl_t>> fri_coef, fri_vals;
+  std::vector<Batch> fri_trees;  // only dig/level_off/cap used
+  DBuf<unsigned long long> pow_result;
+  DBuf<uint64_t> gather_ptrs;
+  DBuf<gl_t> gather_out;
+  size_t gather_cap = 0;
+  // coset sharding across ranks (one process per GPU); world = 1: everything local
+  int shard_rank = 0, shard_world = 1;
+  p2gpu_allgather_fn shard_fn = nullptr;
+  void *shard_ctx = nullptr;
+  DBuf<gl_t> xchg_recv;
+  // knobs
+  uint64_t pow_hint = UINT64_MAX;
+  int profile = 0;
+  int self_check = 1;
+  std::map<std::string, KernelStat> kstats;
+  std::vector<PendingEv> pending;
+  std::vector<hipEvent_t> event_pool;
+};
+
+}  // namespace p2
+
+struct p2gpu_circuit : p2::CircuitState {};
+
+namespace p2 {
+// blob header + gate table + (optional) cap + k_is -> the host-side fields of the handle; leaves
+// *off at the constants table.  Used by p2gpu_circuit_create and p2gpu_verifier_create.
+int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off, const uint8_t **cap_in);
+// the verifier's plonk identity at zeta on the opened values (verify.hip); also the prover's self-check
+bool plonk_identity_holds(const p2gpu_circuit *c, const std::vector<ext_t> &op, const gl_t *betas, const gl_t *gammas,
+                          const gl_t *alphas, ext_t zeta, const gl_t pih[4]);
+}  // namespace p2

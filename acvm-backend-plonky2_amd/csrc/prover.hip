@@ -9,9 +9,7 @@
 // opening values back from the device.  Transcript order: SURVEY.md C.4.
 // The product path never touches oracle/; without a HIP device every entry
 // point fails with P2GPU_E_DEVICE.
-#include "internal.hpp"
-#include "poseidon.hpp"
-#include "../../include/p2gpu.h"
+#include "circuit.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cstdarg>
@@ -24,13 +22,10 @@
 using namespace p2;
 
 namespace {
-
 thread_local std::string g_err;
 }  // namespace
 namespace p2 {
 thread_local Prof *g_prof = nullptr;
-}
-namespace {
 void set_err(const char *fmt, ...) {
   char buf[512];
   va_list ap;
@@ -39,6 +34,8 @@ void set_err(const char *fmt, ...) {
   va_end(ap);
   g_err = buf;
 }
+}  // namespace p2
+namespace {
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
     hipError_t e_ = (expr);                                                                    \
@@ -70,146 +67,10 @@ double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// ---- host transcript (iop/challenger.rs, Challenger<F, KeccakHash<25>>) ----
-struct Challenger {
-  gl_t state[12];
-  gl_t in[8];
-  int n_in = 0;
-  gl_t out[8];
-  int n_out = 0;
-  Challenger() { memset(state, 0, sizeof state); }
-  void duplex() {
-    for (int i = 0; i < n_in; i++) state[i] = in[i];
-    n_in = 0;
-    keccak_permutation12(state);
-    for (int i = 0; i < 8; i++) out[i] = state[i];
-    n_out = 8;
-  }
-  void observe(gl_t e) {
-    n_out = 0;
-    in[n_in++] = e;
-    if (n_in == 8) duplex();
-  }
-  void observe_digest(const dig_t &d) {
-    gl_t e[4];
-    dig_to_elems(d, e);
-    for (int i = 0; i < 4; i++) observe(e[i]);
-  }
-  void observe_cap(const std::vector<dig_t> &cap) {
-    for (auto &d : cap) observe_digest(d);
-  }
-  void observe_ext(ext_t e) {
-    observe(e.c0);
-    observe(e.c1);
-  }
-  gl_t get() {
-    if (n_in != 0 || n_out == 0) duplex();
-    return out[--n_out];
-  }
-  ext_t get_ext() {
-    gl_t a = get();
-    gl_t b = get();
-    return ext_make(a, b);
-  }
-};
 
-dig_t host_hash_no_pad(const std::vector<gl_t> &v) {
-  uint64_t h[4];
-  keccak256_words(v.data(), v.size(), h);
-  return dig_from_state(h);
-}
-
-template <class T>
-struct DBuf {
-  T *p = nullptr;
-  size_t count = 0;
-  hipError_t alloc(size_t n) {
-    count = n;
-    if (n == 0) return hipSuccess;
-    return hipMalloc((void **)&p, n * sizeof(T));
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-  }
-};
-
-// one committed polynomial batch (plonky2 PolynomialBatch), GPU layout
-struct Batch {
-  uint32_t cols = 0, d = 0;
-  uint32_t ncl = 0;   // cosets stored locally (all 2^rate_bits, or this rank's share when sharded)
-  CosetMap cm;        // local coset z <-> global coset cm.first + z * cm.stride
-  DBuf<gl_t> coeffs;  // [cols][n], bit-reversed positions
-  DBuf<gl_t> lde;     // [C][cols][n]
-  DBuf<dig_t> dig;    // all tree levels, level l at level_off[l], layout [C][n >> l]
-  std::vector<size_t> level_off;
-  std::vector<dig_t> cap;  // plonky2 order
-  void release() {
-    coeffs.release();
-    lde.release();
-    dig.release();
-  }
-};
-
-struct KernelStat {
-  double ms = 0, bytes = 0;
-  uint64_t launches = 0;
-};
-struct PendingEv {
-  const char *name;
-  double bytes;
-  hipEvent_t a, b;
-};
 
 }  // namespace
 
-struct p2gpu_circuit {
-  // parameters
-  uint32_t d, W, R, NC, num_selectors, K, QF, rate_bits, cap_h, pow_bits, num_queries, n_steps, arity[8];
-  uint32_t num_gates, num_pi, flags, PP, nchunks;
-  size_t n, N;
-  uint32_t C;  // cosets = 2^rate_bits
-  std::vector<GateDesc> gates;
-  std::vector<gl_t> k_is;
-  uint32_t nterms = 0, max_gate_constraints = 0;
-  uint32_t gate_groups = 1;  // quotient kernel: 1, or 4 when the gate set is heavy
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;  // H2D of the witness, overlapped with the transforms of earlier columns
-  std::vector<hipEvent_t> copy_events;
-  bool wires_ntt_done = false;        // set by p2gpu_prove: coefficients + LDE of the wires already enqueued
-  // tables
-  DBuf<gl_t> tw_fwd, tw_inv, scale, inv_scale, d_kis, d_sigmas, fri_scale, qconst;
-  DBuf<GateDesc> d_gates;
-  DBuf<uint8_t> d_row_gate;   // [n] gate index of every row (from the selector columns)
-  DBuf<gl_t> d_gconsts, d_prc; // gate-constant columns [NC - num_selectors][n]; Poseidon round constants
-  NttPlan *plan_inv = nullptr, *plan_fwd = nullptr;  // size n: values->coeffs (DIF, w^-1), coeffs->values (DIT)
-  std::vector<NttPlan *> fri_plans;                   // DIT plans of the FRI step sizes
-  // oracles
-  Batch cs, wires, zp, quot;
-  dig_t circuit_digest;
-  gl_t poseidon_rc[360];
-  // work buffers
-  DBuf<gl_t> wires_vals, zp_vals, cp, rowprod, scan_tmp, apow, qvals, qtmp, pw, partial, ext_apow, f01, f01v, fv;
-  std::vector<DBuf<gl_t>> fri_coef, fri_vals;
-  std::vector<Batch> fri_trees;  // only dig/level_off/cap used
-  DBuf<unsigned long long> pow_result;
-  DBuf<uint64_t> gather_ptrs;
-  DBuf<gl_t> gather_out;
-  size_t gather_cap = 0;
-  // coset sharding across ranks (one process per GPU); world = 1: everything local
-  int shard_rank = 0, shard_world = 1;
-  p2gpu_allgather_fn shard_fn = nullptr;
-  void *shard_ctx = nullptr;
-  DBuf<gl_t> xchg_recv;
-  // knobs
-  uint64_t pow_hint = UINT64_MAX;
-  int profile = 0;
-  int self_check = 1;
-  std::map<std::string, KernelStat> kstats;
-  std::vector<PendingEv> pending;
-  std::vector<hipEvent_t> event_pool;
-};
 
 namespace {
 
@@ -408,63 +269,6 @@ void path_positions(const Batch &b, uint32_t C, unsigned lgC, size_t m0, unsigne
   (void)C;
 }
 
-// The verifier's plonk identity at zeta, on the opened values (plonk/verifier.rs
-// verify_with_challenges + vanishing_poly.rs eval_vanishing_poly over the extension):
-//   vanishing_c(zeta) == Z_H(zeta) * sum_m zeta^(n m) * t_{c,m}(zeta)        for each challenge c.
-// It fails exactly when the witness does not satisfy the circuit (with overwhelming
-// probability); upstream only finds that out in its witness generator, which stays in Rust.
-struct CollectOut {
-  std::vector<ext_t> *v;
-  void emit(ext_t c) { v->push_back(c); }
-};
-bool plonk_identity_holds(const p2gpu_circuit *c, const std::vector<ext_t> &op, const gl_t *betas, const gl_t *gammas,
-                          const gl_t *alphas, ext_t zeta, const gl_t pih[4]) {
-  const uint32_t K = c->K, R = c->R, W = c->W, NC = c->NC, QF = c->QF, PP = c->PP, nchunks = c->nchunks;
-  const uint32_t ncs = NC + R, nzp = K * (1 + PP), nall = ncs + W + nzp + K * QF;
-  const ext_t *o_const = op.data(), *o_sig = o_const + NC, *o_wires = o_sig + R, *o_zs = o_wires + W;
-  const ext_t *o_pp = o_zs + K, *o_quot = o_pp + K * PP, *o_zs_next = op.data() + nall;
-  ext_t zn = zeta;
-  for (uint32_t i = 0; i < c->d; i++) zn = ext_mul(zn, zn);
-  const ext_t z_h = ext_sub(zn, ext_from(1));
-  const ext_t l0 = ext_mul(z_h, ext_inv(ext_scale(ext_sub(zeta, ext_from(1)), (gl_t)c->n)));
-  std::vector<ext_t> terms;
-  for (uint32_t k = 0; k < K; k++) terms.push_back(ext_mul(l0, ext_sub(o_zs[k], ext_from(1))));
-  for (uint32_t k = 0; k < K; k++)
-    for (uint32_t m = 0; m < nchunks; m++) {
-      const ext_t prev = m == 0 ? o_zs[k] : o_pp[k * PP + m - 1];
-      const ext_t next = m == nchunks - 1 ? o_zs_next[k] : o_pp[k * PP + m];
-      ext_t np = ext_from(1), dp = ext_from(1);
-      for (uint32_t j = m * QF; j < (m + 1) * QF && j < R; j++) {
-        const ext_t s_id = ext_scale(zeta, c->k_is[j]);
-        np = ext_mul(np, ext_add(ext_add(o_wires[j], ext_scale(s_id, betas[k])), ext_from(gammas[k])));
-        dp = ext_mul(dp, ext_add(ext_add(o_wires[j], ext_scale(o_sig[j], betas[k])), ext_from(gammas[k])));
-      }
-      terms.push_back(ext_sub(ext_mul(prev, np), ext_mul(next, dp)));
-    }
-  std::vector<ext_t> gate_terms(c->max_gate_constraints, ext_from(0)), cons;
-  ext_t pih_e[4];
-  for (int i = 0; i < 4; i++) pih_e[i] = ext_from(pih[i]);
-  auto Wf = [&](uint32_t col) { return o_wires[col]; };
-  auto LC = [&](uint32_t i) { return o_const[c->num_selectors + i]; };
-  for (uint32_t gi = 0; gi < c->num_gates; gi++) {
-    const GateDesc &g = c->gates[gi];
-    if (!g.num_constraints) continue;
-    const ext_t f = gate_filter<ExtOps>(g, gi, c->num_selectors, o_const[g.sel_index]);
-    cons.clear();
-    CollectOut out{&cons};
-    eval_gate<ExtOps, true>(g, Wf, LC, pih_e, c->poseidon_rc, out);
-    for (size_t k = 0; k < cons.size() && k < gate_terms.size(); k++)
-      gate_terms[k] = ext_add(gate_terms[k], ext_mul(f, cons[k]));
-  }
-  terms.insert(terms.end(), gate_terms.begin(), gate_terms.end());
-  for (uint32_t k = 0; k < K; k++) {
-    ext_t van = ext_from(0), qz = ext_from(0);
-    for (size_t t = terms.size(); t-- > 0;) van = ext_add(ext_scale(van, alphas[k]), terms[t]);
-    for (uint32_t m = QF; m-- > 0;) qz = ext_add(ext_mul(qz, zn), o_quot[k * QF + m]);
-    if (!ext_eq(van, ext_mul(z_h, qz))) return false;
-  }
-  return true;
-}
 
 int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
                size_t *proof_len, p2gpu_timings *tm, double h2d_ms) {
@@ -953,6 +757,71 @@ uint32_t gate_num_constraints(uint32_t kind, const uint32_t p[4]) {
 
 }  // namespace
 
+namespace p2 {
+int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off_out, const uint8_t **cap_in) {
+  if (len < 256) { set_err("blob too short"); return P2GPU_E_BLOB; }
+  uint32_t h[64];
+  memcpy(h, blob, sizeof h);
+  if (h[0] != 0x43473250u || h[1] != 1) { set_err("bad blob magic/version"); return P2GPU_E_BLOB; }
+  c->d = h[2]; c->W = h[3]; c->R = h[4]; c->NC = h[5]; c->num_selectors = h[6]; c->K = h[7]; c->QF = h[8];
+  c->rate_bits = h[9]; c->cap_h = h[10]; c->pow_bits = h[11]; c->num_queries = h[12]; c->n_steps = h[13];
+  for (int i = 0; i < 8; i++) c->arity[i] = h[14 + i];
+  const uint32_t hasher = h[22];
+  c->num_gates = h[23]; c->num_pi = h[24]; c->flags = h[25]; c->PP = h[26];
+  auto fail = [&](int rc, const char *msg) {
+    set_err("%s", msg);
+    return rc;
+  };
+  if (hasher != 0) return fail(P2GPU_E_BLOB, "unsupported hasher (only KeccakHash<25>)");
+  if (c->d < 1 || c->d > 24 || c->K < 1 || c->K > 2 || c->rate_bits < 1 || c->rate_bits > 3 || c->cap_h < c->rate_bits ||
+      c->cap_h > c->rate_bits + c->d || c->n_steps > 8 || c->R > MAX_ROUTED || c->QF == 0 || c->num_gates > MAX_GATES ||
+      c->num_queries > 64 || c->W < c->R || (1u << c->rate_bits) != c->QF || c->pow_bits > 32)
+    return fail(P2GPU_E_BLOB, "unsupported circuit parameters");
+  c->n = (size_t)1 << c->d;
+  c->N = c->n << c->rate_bits;
+  c->C = 1u << c->rate_bits;
+  c->nchunks = (c->R + c->QF - 1) / c->QF;
+  if (c->nchunks > 16 || c->PP != c->nchunks - 1) return fail(P2GPU_E_BLOB, "unsupported circuit parameters");
+  size_t off = 256;
+  if (len < off + (size_t)c->num_gates * 48) return fail(P2GPU_E_BLOB, "blob truncated (gate table)");
+  c->max_gate_constraints = 0;
+  c->gates.clear();
+  for (uint32_t i = 0; i < c->num_gates; i++) {
+    uint32_t g[12];
+    memcpy(g, blob + off, sizeof g);
+    off += sizeof g;
+    GateDesc G;
+    G.kind = g[0];
+    memcpy(G.p, &g[1], 16);
+    G.sel_index = g[5]; G.group_start = g[6]; G.group_end = g[7]; G.num_constraints = g[8]; G.degree = g[9];
+    G.num_constants = g[10]; G.pad = 0;
+    if (G.kind >= G_KIND_COUNT) return fail(P2GPU_E_BLOB, "unsupported gate kind in blob");
+    if (G.num_constraints != gate_num_constraints(G.kind, G.p)) return fail(P2GPU_E_BLOB, "gate constraint count mismatch");
+    if (G.kind == G_RANDOM_ACCESS && G.p[0] > 6) return fail(P2GPU_E_BLOB, "RandomAccessGate bits > 6 unsupported");
+    if (G.sel_index >= c->num_selectors || G.group_end > c->num_gates) return fail(P2GPU_E_BLOB, "bad selector info");
+    c->max_gate_constraints = std::max(c->max_gate_constraints, G.num_constraints);
+    c->gates.push_back(G);
+  }
+  *cap_in = nullptr;
+  if (c->flags & 2) {
+    if (len < off + ((size_t)32 << c->cap_h)) return fail(P2GPU_E_BLOB, "blob truncated (cap)");
+    *cap_in = blob + off;
+    off += (size_t)32 << c->cap_h;
+  }
+  if (len < off + 8 * (size_t)c->R) return fail(P2GPU_E_BLOB, "blob truncated (k_is)");
+  c->k_is.resize(c->R);
+  memcpy(c->k_is.data(), blob + off, 8 * (size_t)c->R);
+  off += 8 * (size_t)c->R;
+  if (c->flags & 1) {
+    memset(&c->circuit_digest, 0, sizeof(dig_t));
+    memcpy(c->circuit_digest.w, &h[32], 25);
+  }
+  poseidon_round_constants_host(c->poseidon_rc);
+  *off_out = off;
+  return P2GPU_OK;
+}
+}  // namespace p2
+
 // scratch allocations of the stage-level operators
 namespace {
 struct Scratch {
@@ -1018,20 +887,13 @@ size_t p2gpu_proof_size_bound(const p2gpu_circuit *c) {
 int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c) {
   if (!blob || !out_c) return P2GPU_E_ARG;
   if (int rc = ensure_device()) return rc;
-  if (len < 256) { set_err("blob too short"); return P2GPU_E_BLOB; }
-  uint32_t h[64];
-  memcpy(h, blob, sizeof h);
-  if (h[0] != 0x43473250u || h[1] != 1) { set_err("bad blob magic/version"); return P2GPU_E_BLOB; }
   p2gpu_circuit *c = new p2gpu_circuit();
-  c->d = h[2]; c->W = h[3]; c->R = h[4]; c->NC = h[5]; c->num_selectors = h[6]; c->K = h[7]; c->QF = h[8];
-  c->rate_bits = h[9]; c->cap_h = h[10]; c->pow_bits = h[11]; c->num_queries = h[12]; c->n_steps = h[13];
-  for (int i = 0; i < 8; i++) c->arity[i] = h[14 + i];
-  uint32_t hasher = h[22];
-  c->num_gates = h[23]; c->num_pi = h[24]; c->flags = h[25]; c->PP = h[26];
-  c->n = (size_t)1 << c->d;
-  c->N = c->n << c->rate_bits;
-  c->C = 1u << c->rate_bits;
-  c->nchunks = (c->R + c->QF - 1) / c->QF;
+  size_t off = 0;
+  const uint8_t *cap_in = nullptr;
+  if (int rc = circuit_parse(blob, len, c, &off, &cap_in)) {
+    delete c;
+    return rc;
+  }
   c->device = g_device;
   auto fail = [&](int rc, const char *msg) {
     set_err("%s", msg);
@@ -1039,30 +901,6 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     delete c;
     return rc;
   };
-  if (hasher != 0) return fail(P2GPU_E_BLOB, "unsupported hasher (only KeccakHash<25>)");
-  if (c->d < 1 || c->d > 24 || c->K < 1 || c->K > 2 || c->rate_bits < 1 || c->rate_bits > 3 || c->cap_h < c->rate_bits ||
-      c->cap_h > c->rate_bits + c->d || c->n_steps > 8 || c->R > MAX_ROUTED || c->nchunks > 16 || c->PP != c->nchunks - 1 ||
-      c->num_gates > MAX_GATES || c->num_queries > 64 || c->W < c->R || (1u << c->rate_bits) != c->QF)
-    return fail(P2GPU_E_BLOB, "unsupported circuit parameters");
-  size_t off = 256;
-  if (len < off + (size_t)c->num_gates * 48) return fail(P2GPU_E_BLOB, "blob truncated (gate table)");
-  c->max_gate_constraints = 0;
-  for (uint32_t i = 0; i < c->num_gates; i++) {
-    uint32_t g[12];
-    memcpy(g, blob + off, sizeof g);
-    off += sizeof g;
-    GateDesc G;
-    G.kind = g[0];
-    memcpy(G.p, &g[1], 16);
-    G.sel_index = g[5]; G.group_start = g[6]; G.group_end = g[7]; G.num_constraints = g[8]; G.degree = g[9];
-    G.num_constants = g[10]; G.pad = 0;
-    if (G.kind >= G_KIND_COUNT) return fail(P2GPU_E_BLOB, "unsupported gate kind in blob");
-    if (G.num_constraints != gate_num_constraints(G.kind, G.p)) return fail(P2GPU_E_BLOB, "gate constraint count mismatch");
-    if (G.kind == G_RANDOM_ACCESS && G.p[0] > 6) return fail(P2GPU_E_BLOB, "RandomAccessGate bits > 6 unsupported");
-    if (G.sel_index >= c->num_selectors || G.group_end > c->num_gates) return fail(P2GPU_E_BLOB, "bad selector info");
-    c->max_gate_constraints = std::max(c->max_gate_constraints, G.num_constraints);
-    c->gates.push_back(G);
-  }
   c->nterms = c->K + c->K * c->nchunks + c->max_gate_constraints;
   {
     // heavy gate mixes: split the gates over 4 waves that share a row tile (plonk.hip); greedy
@@ -1086,20 +924,12 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
       load[best] += cost(c->gates[gi]);
     }
   }
-  const uint8_t *cap_in = nullptr;
-  if (c->flags & 2) {
-    cap_in = blob + off;
-    off += (size_t)32 << c->cap_h;
-  }
   const size_t n = c->n;
-  size_t need = off + 8 * ((size_t)c->R + (size_t)c->NC * n + (size_t)c->R * n);
-  if (len < need) return fail(P2GPU_E_BLOB, "blob truncated (tables)");
-  const gl_t *k_is = (const gl_t *)(blob + off);
-  off += 8 * (size_t)c->R;
+  if (len < off + 8 * ((size_t)c->NC * n + (size_t)c->R * n)) return fail(P2GPU_E_BLOB, "blob truncated (tables)");
+  const gl_t *k_is = c->k_is.data();
   const gl_t *constants = (const gl_t *)(blob + off);
   off += 8 * (size_t)c->NC * n;
   const gl_t *sigmas = (const gl_t *)(blob + off);
-  c->k_is.assign(k_is, k_is + c->R);
 
   // ---- device state ----
   auto H = [&](hipError_t e, const char *what) -> int {
@@ -1116,7 +946,6 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     return P2GPU_E_DEVICE;                            \
   }
   CK(hipSetDevice(c->device), "hipSetDevice");
-  poseidon_round_constants_host(c->poseidon_rc);
   if (poseidon_upload_constants()) return fail(P2GPU_E_DEVICE, "uploading Poseidon constants failed");
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
   CK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -1141,19 +970,6 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   fill_powers(st, c->tw_inv.p, gl_inv(wn), (uint32_t)half);
   fill_coset_scale(st, c->scale.p, GL_GEN, wN, d, C, 1);
   fill_coset_scale(st, c->inv_scale.p, gl_inv(GL_GEN), gl_inv(wN), d, C, 1);
-  CK(c->qconst.alloc(24), "alloc qconst");
-  {
-    // ZeroPolyOnCoset: Z_H on the LDE coset has period 2^rate_bits
-    gl_t qc[24];
-    memset(qc, 0, sizeof qc);
-    gl_t wC = gl_root(c->rate_bits), gn = gl_pow(GL_GEN, n);
-    for (uint32_t r = 0; r < C; r++) {
-      qc[r] = gl_mul(GL_GEN, gl_pow(wN, r));
-      qc[8 + r] = gl_sub(gl_mul(gn, gl_pow(wC, r)), 1);
-      qc[16 + r] = gl_inv(qc[8 + r]);
-    }
-    CK(hipMemcpy(c->qconst.p, qc, sizeof qc, hipMemcpyHostToDevice), "copy qconst");
-  }
   CK(c->qconst.alloc(24), "alloc qconst");
   {
     // ZeroPolyOnCoset: Z_H on the LDE coset has period 2^rate_bits
@@ -1271,10 +1087,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     for (size_t i = 0; i < c->cs.cap.size(); i++)
       if (memcmp(cap_in + 32 * i, c->cs.cap[i].w, 25)) return fail(P2GPU_E_CAP_MISMATCH, "constants_sigmas cap mismatch");
   }
-  if (c->flags & 1) {
-    memset(&c->circuit_digest, 0, sizeof(dig_t));
-    memcpy(c->circuit_digest.w, &h[32], 25);
-  } else {
+  if (!(c->flags & 1)) {
     // circuit_builder.rs build(): H::hash_no_pad(cap.flatten() || hash_pad([]).to_vec() || [degree_bits])  [P2-recall]
     std::vector<gl_t> parts;
     for (auto &dg : c->cs.cap) {
@@ -1300,9 +1113,11 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
 
 void p2gpu_circuit_destroy(p2gpu_circuit *c) {
   if (!c) return;
-  (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
-  circuit_release(c);
+  if (c->device >= 0) {  // a verifier-only handle owns nothing on a device
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    circuit_release(c);
+  }
   delete c;
 }
 
@@ -1319,6 +1134,7 @@ int p2gpu_circuit_digest(const p2gpu_circuit *c, uint8_t out[25]) {
 
 int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) {
   if (!c || !key) return P2GPU_E_ARG;
+  if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
   std::string k(key);
   if (k == "pow_hint") c->pow_hint = value;
   else if (k == "self_check") c->self_check = (int)value;
@@ -1338,6 +1154,7 @@ int p2gpu_circuit_set_shard(p2gpu_circuit *c, int rank, int world, p2gpu_allgath
     set_err("bad shard configuration: rank %d of %d (cosets %u)", rank, world, c ? c->C : 0u);
     return P2GPU_E_ARG;
   }
+  if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
   HIP_TRY(hipSetDevice(c->device));
   c->shard_rank = rank;
   c->shard_world = world;
@@ -1371,6 +1188,7 @@ int p2gpu_circuit_set_shard(p2gpu_circuit *c, int rank, int world, p2gpu_allgath
 // entries "name\0" (64 B each) + total ms + launch count; returns the number of entries
 int p2gpu_kernel_stats(p2gpu_circuit *c, char *names, double *ms, double *bytes, uint64_t *launches, int cap) {
   if (!c) return P2GPU_E_ARG;
+  if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   flush_kstats(c);
@@ -1388,6 +1206,7 @@ int p2gpu_kernel_stats(p2gpu_circuit *c, char *names, double *ms, double *bytes,
 
 int p2gpu_fill_witness(p2gpu_circuit *c, uint64_t *wires_dev) {
   if (!c || !wires_dev) return P2GPU_E_ARG;
+  if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
   HIP_TRY(hipSetDevice(c->device));
   fill_witness(c->stream, wires_dev, c->d_row_gate.p, c->d_gates.p, c->d_gconsts.p, c->d_prc.p, c->d, c->NC - c->num_selectors,
                c->W);
@@ -1398,6 +1217,7 @@ int p2gpu_fill_witness(p2gpu_circuit *c, uint64_t *wires_dev) {
 int p2gpu_prove_routed(p2gpu_circuit *c, const uint64_t *routed, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
                        size_t *proof_len, p2gpu_timings *tm) {
   if (!c || !routed || !proof_out || !proof_len) return P2GPU_E_ARG;
+  if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
   HIP_TRY(hipSetDevice(c->device));
   double t0 = now_ms();
   // only the routed columns cross PCIe; every other column is gate-internal and derived on the GPU
@@ -1413,12 +1233,14 @@ int p2gpu_prove_routed(p2gpu_circuit *c, const uint64_t *routed, const uint64_t 
 int p2gpu_prove_dev(p2gpu_circuit *c, const uint64_t *wires_dev, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
                     size_t *proof_len, p2gpu_timings *tm) {
   if (!c || !wires_dev || !proof_out || !proof_len) return P2GPU_E_ARG;
+  if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
   return prove_impl(c, wires_dev, pis, n_pi, proof_out, proof_len, tm, 0.0);
 }
 
 int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
                 size_t *proof_len, p2gpu_timings *tm) {
   if (!c || !wires || !proof_out || !proof_len) return P2GPU_E_ARG;
+  if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
   HIP_TRY(hipSetDevice(c->device));
   // The witness crosses PCIe in column chunks on a copy stream; the inverse transform and the
   // LDE of a chunk run while the next chunk is still in flight (values -> coefficients -> LDE are

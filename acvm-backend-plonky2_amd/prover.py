@@ -87,6 +87,9 @@ def load_library():
     lib.p2gpu_prove_dev.argtypes = lib.p2gpu_prove.argtypes
     lib.p2gpu_prove_routed.argtypes = lib.p2gpu_prove.argtypes
     lib.p2gpu_fill_witness.argtypes = [vp, vp]
+    lib.p2gpu_verify.argtypes = [vp, u8p, sz]
+    lib.p2gpu_circuit_export_vk.argtypes = [vp, u8p, ctypes.POINTER(sz)]
+    lib.p2gpu_verifier_create.argtypes = [u8p, sz, ctypes.POINTER(vp)]
     lib.p2gpu_circuit_set.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64]
     lib.p2gpu_circuit_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int, _ALLGATHER_FN, vp]
     lib.p2gpu_kernel_stats.argtypes = [vp, ctypes.c_char_p, vp, vp, vp, ctypes.c_int]
@@ -263,6 +266,72 @@ class CircuitData:
         _check(self._lib.p2gpu_prove_routed(self._h, r.ctypes.data, pis.ctypes.data, len(pis), out.ctypes.data,
                                             ctypes.byref(plen), ctypes.byref(tm)))
         return ProofWithPublicInputs(out[:plen.value].tobytes(), {f: getattr(tm, f) for f, _ in _Timings._fields_})
+
+    def verify(self, proof):
+        """``circuit_data.verify(proof)``: raises P2GpuError(P2GPU_E_VERIFY) when the proof is
+        rejected (the failed check is the message), returns None when it is accepted."""
+        _verify(self._lib, self._h, proof)
+
+    def verifier_data(self):
+        """``circuit_data.verifier_data()``: the verifier's share of the circuit."""
+        return VerifierCircuitData(self.verifier_blob())
+
+    def verifier_blob(self):
+        """Bytes of the verifier's share (header, gate table, constants_sigmas cap, digest, k_is)."""
+        n = ctypes.c_size_t(0)
+        _check(self._lib.p2gpu_circuit_export_vk(self._h, None, ctypes.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        _check(self._lib.p2gpu_circuit_export_vk(self._h, out.ctypes.data, ctypes.byref(n)))
+        return out[:n.value].tobytes()
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.p2gpu_circuit_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _verify(lib, handle, proof):
+    data = proof.to_bytes() if hasattr(proof, "to_bytes") else bytes(proof)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    _check(lib.p2gpu_verify(handle, buf.ctypes.data if buf.size else None, buf.size))
+
+
+class VerifierCircuitData:
+    """Verifier-only handle (``VerifierCircuitData`` of the reference's verify action,
+    plonky2-backend/src/actions/verify_action.rs:11-17).  Host code only: works without a GPU."""
+
+    def __init__(self, blob):
+        lib = load_library()
+        self._lib = lib
+        self._blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8))
+        self._h = ctypes.c_void_p()
+        _check(lib.p2gpu_verifier_create(self._blob.ctypes.data, self._blob.nbytes, ctypes.byref(self._h)))
+        hdr = self._blob[:256].view(np.uint32)
+        self.degree_bits = int(hdr[2])
+        self.cap_height = int(hdr[10])
+        self.num_public_inputs = int(hdr[24])
+
+    def to_bytes(self):
+        return self._blob.tobytes()
+
+    def circuit_digest(self):
+        out = np.zeros(25, dtype=np.uint8)
+        _check(self._lib.p2gpu_circuit_digest(self._h, out.ctypes.data))
+        return out.tobytes()
+
+    def constants_sigmas_cap(self):
+        out = np.zeros(25 << self.cap_height, dtype=np.uint8)
+        _check(self._lib.p2gpu_circuit_cap(self._h, out.ctypes.data))
+        return out.tobytes()
+
+    def verify(self, proof):
+        _verify(self._lib, self._h, proof)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -1,14 +1,15 @@
 /*
  * p2gpu-prove -- stand-alone caller of the C ABI (include/p2gpu.h), plain C, no Python:
  *
- *     p2gpu-prove <circuit.blob> <wires.bin> <proof.bin> [public_inputs.bin] [--routed]
+ *     p2gpu-prove <circuit.blob> <wires.bin> <proof.bin> [public_inputs.bin] [--routed] [--vk <vk.blob>]
  *
  * The counterpart of `plonky2-backend prove -b <acir> -w <witness> -o <proof>`
  * (plonky2-backend/src/argument_parsing.rs:36-41 -> actions/prove_action.rs:27-43) below the
  * translation layer: the circuit blob is what the Rust side exports once per circuit and
  * wires.bin is the dense witness matrix [num_wires][n] of little-endian u64 (with --routed only
  * the [num_routed_wires][n] routed columns; the rest is derived on the GPU).  Writes the
- * uncompressed ProofWithPublicInputs bytes.  Exit code 0 = ok, 1 = usage/IO, 2 = library error.
+ * uncompressed ProofWithPublicInputs bytes; --vk also writes the verifier's share of the circuit for
+ * p2gpu-verify (the reference's `write_vk`, actions/write_vk_action.rs:65-81).  Exit code 0 = ok, 1 = usage/IO, 2 = library error.
  */
 #include "../../include/p2gpu.h"
 #include <stdio.h>
@@ -33,13 +34,14 @@ static void *slurp(const char *path, size_t *len) {
 
 int main(int argc, char **argv) {
   int routed = 0, npos = 0;
-  const char *pos[4] = {0, 0, 0, 0};
+  const char *pos[4] = {0, 0, 0, 0}, *vk_path = NULL;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--routed")) routed = 1;
+    else if (!strcmp(argv[i], "--vk") && i + 1 < argc) vk_path = argv[++i];
     else if (npos < 4) pos[npos++] = argv[i];
   }
   if (npos < 3) {
-    fprintf(stderr, "usage: %s <circuit.blob> <wires.bin> <proof.bin> [public_inputs.bin] [--routed]\n", argv[0]);
+    fprintf(stderr, "usage: %s <circuit.blob> <wires.bin> <proof.bin> [public_inputs.bin] [--routed] [--vk <vk.blob>]\n", argv[0]);
     return 1;
   }
   size_t blob_len, wires_len, pi_len = 0;
@@ -55,6 +57,18 @@ int main(int argc, char **argv) {
   if (rc) {
     fprintf(stderr, "p2gpu_circuit_create: %d: %s\n", rc, p2gpu_last_error());
     return 2;
+  }
+  if (vk_path) {
+    size_t vk_len = 0;
+    p2gpu_circuit_export_vk(c, NULL, &vk_len);
+    uint8_t *vk = malloc(vk_len);
+    FILE *vf = fopen(vk_path, "wb");
+    if (!vk || p2gpu_circuit_export_vk(c, vk, &vk_len) || !vf || fwrite(vk, 1, vk_len, vf) != vk_len) {
+      fprintf(stderr, "cannot write %s\n", vk_path);
+      return 1;
+    }
+    fclose(vf);
+    free(vk);
   }
   size_t cap = p2gpu_proof_size_bound(c), len = cap;
   uint8_t *proof = malloc(cap);

@@ -78,6 +78,7 @@ extern "C" {
 #define P2GPU_E_CAP_MISMATCH -6       /* constants_sigmas cap differs from the one in the blob */
 #define P2GPU_E_ARG -7
 #define P2GPU_E_NOT_INIT -8
+#define P2GPU_E_VERIFY -9             /* p2gpu_verify: the proof is not valid for this circuit */
 
 typedef struct p2gpu_circuit p2gpu_circuit;
 
@@ -124,6 +125,20 @@ int p2gpu_fill_witness(p2gpu_circuit *c, uint64_t *wires_dev);
  * all gate-internal, so they are filled on the GPU instead of crossing PCIe (80 of 234 columns). */
 int p2gpu_prove_routed(p2gpu_circuit *c, const uint64_t *routed, const uint64_t *public_inputs, uint32_t n_pi,
                        uint8_t *proof_out, size_t *proof_len, p2gpu_timings *opt_timings);
+
+/* ---- verification (host code only; needs no GPU) ------------------------------------------------
+ * The counterpart of the reference's `verify` action (plonky2-backend/src/actions/verify_action.rs:11-17)
+ * and of the `circuit_data.verify(proof)` assertion its tests end with (tests/factories/utils.rs:26-27),
+ * on the uncompressed proof bytes p2gpu_prove writes.  Returns P2GPU_OK or P2GPU_E_VERIFY (the failed
+ * check is in p2gpu_last_error).  Accepts a prover handle or a verifier-only one. */
+int p2gpu_verify(const p2gpu_circuit *c, const uint8_t *proof, size_t len);
+/* The verifier's share of a circuit -- header, gate table, constants_sigmas cap, circuit digest, k_is
+ * (the blob prefix up to the constants table, flags 0b11) -- like the VK file of
+ * actions/write_vk_action.rs:65-81.  out == NULL: only report the size in *len. */
+int p2gpu_circuit_export_vk(const p2gpu_circuit *c, uint8_t *out, size_t *len);
+/* Handle from such a blob (a full circuit blob with flags 0b11 works too: only its prefix is read).
+ * No device is touched; the prove / fill / shard entry points reject it with P2GPU_E_ARG. */
+int p2gpu_verifier_create(const uint8_t *blob, size_t len, p2gpu_circuit **out);
 
 /* optional knobs: "pow_hint" (u64; UINT64_MAX = grind), "self_check" (0/1, default 1: evaluate the
  * verifier's plonk identity at zeta on the host before FRI and return P2GPU_E_UNSATISFIED when the

@@ -91,6 +91,11 @@ def test_proof_bytes_match_oracle(pkg, orc, gpu, d, mix, seed):
     assert got.timings["pow_witness"] == tr.pow_witness
     assert got.to_bytes() == expect
     assert oc.verify(got.to_bytes())
+    # the library's own verifier, on the prover handle and on the exported verifier key
+    cd.verify(got)
+    vd = cd.verifier_data()
+    vd.verify(got)
+    assert vd.circuit_digest() == oc.digest() and vd.constants_sigmas_cap() == oc.cap()
     # device-resident witness (torch tensor) goes through p2gpu_prove_dev: same bytes
     import torch
 
@@ -173,6 +178,9 @@ def test_unsatisfied_witness_gives_rejected_proof(pkg, orc, gpu):
     proof = cd.prove(bad).to_bytes()
     assert proof == oc.prove(bad)[0]
     assert not oc.verify(proof)
+    with pytest.raises(pkg.P2GpuError) as ei:
+        cd.verify(proof)
+    assert ei.value.code == -9
 
 
 def test_error_paths(pkg, gpu):
@@ -205,9 +213,12 @@ def test_larger_configs_are_accepted(pkg, orc, gpu, d, mix):
     proof = cd.prove(wires)
     ov = orc.OracleCircuit(blob, verifier_cap=cd.constants_sigmas_cap(), verifier_digest=cd.circuit_digest())
     assert ov.verify(proof.to_bytes())
+    cd.verify(proof)
     bad = bytearray(proof.to_bytes())
     bad[len(bad) // 2] ^= 1
     assert not ov.verify(bytes(bad))
+    with pytest.raises(pkg.P2GpuError):
+        cd.verify(bytes(bad))
     cd.close()
 
 
@@ -223,11 +234,14 @@ def test_full_size_proof_is_accepted(pkg, orc, gpu, mix):
     proof = cd.prove(wires)
     ov = orc.OracleCircuit(blob, verifier_cap=cd.constants_sigmas_cap(), verifier_digest=cd.circuit_digest())
     assert ov.verify(proof.to_bytes())
+    cd.verifier_data().verify(proof)
     # reproducible, and a tampered opening is rejected
     assert cd.prove(wires).to_bytes() == proof.to_bytes()
     bad = bytearray(proof.to_bytes())
     bad[3 * 16 * 25 + 24] ^= 1
     assert not ov.verify(bytes(bad))
+    with pytest.raises(pkg.P2GpuError):
+        cd.verify(bytes(bad))
     # an unsatisfied witness at full size is rejected too
     w2 = wires.copy()
     w2[7, 12345] = (int(w2[7, 12345]) + 1) % P
@@ -277,11 +291,20 @@ def test_standalone_c_caller(pkg, orc, gpu, tmp_path):
     (tmp_path / "r.bin").write_bytes(np.ascontiguousarray(wires[:80]).tobytes())
     (tmp_path / "pi.bin").write_bytes(pis.tobytes())
     expect, _ = orc.OracleCircuit(blob).prove(wires, public_inputs=pis)
-    for args, out in ((["w.bin"], "p1.bin"), (["r.bin", "--routed"], "p2.bin")):
+    for args, out in ((["w.bin", "--vk", str(tmp_path / "vk.blob")], "p1.bin"), (["r.bin", "--routed"], "p2.bin")):
         cmd = [exe, str(tmp_path / "c.blob"), str(tmp_path / args[0]), str(tmp_path / out), str(tmp_path / "pi.bin")] + args[1:]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         assert (tmp_path / out).read_bytes() == expect
+    # `p2gpu-verify <vk> <proof>`: the reference's write_vk -> prove -> verify round trip in plain C
+    vexe = os.path.join(ROOT, "acvm-backend-plonky2_amd", "p2gpu-verify")
+    r = subprocess.run([vexe, str(tmp_path / "vk.blob"), str(tmp_path / "p1.bin")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "accepted" in r.stderr, r.stderr
+    tampered = bytearray(expect)
+    tampered[-1] ^= 1
+    (tmp_path / "bad.bin").write_bytes(bytes(tampered))
+    r = subprocess.run([vexe, str(tmp_path / "vk.blob"), str(tmp_path / "bad.bin")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and "rejected" in r.stderr
     # a broken blob is reported through the error code + message, not a crash
     (tmp_path / "bad.blob").write_bytes(b"\0" * 300)
     r = subprocess.run([exe, str(tmp_path / "bad.blob"), str(tmp_path / "w.bin"), str(tmp_path / "p3.bin")],

@@ -1,0 +1,147 @@
+"""The product's verifier (libp2gpu.so p2gpu_verify, host code only) against the oracle's prover on a
+CPU-only host: two independently written implementations of the protocol must agree -- the
+product's verifier accepts every proof the oracle's prover writes and rejects every proof the
+oracle's verifier rejects.
+
+Mirrors the reference's `verify` action (plonky2-backend/src/actions/verify_action.rs:11-17) and
+the `circuit_data.verify(proof)` assertion its tests end with (tests/factories/utils.rs:26-27); the
+negatives follow its `should_panic` tests (circuit_translation/tests/test_blackbox.rs:17,36,55).
+"""
+import re
+
+import numpy as np
+import pytest
+
+from conftest import P
+
+
+def vk_blob(blob, cap, digest):
+    """The verifier's share of a synth circuit blob (include/p2gpu.h: header | gate table | cap |
+    k_is, flags 0b11), with the cap and digest the oracle computed on the CPU."""
+    h = blob[:256].copy().view(np.uint32)
+    assert h[25] == 0  # synth blobs carry neither cap nor digest
+    ng, R, cap_h = int(h[23]), int(h[4]), int(h[10])
+    h[25] = 3
+    hb = bytearray(h.tobytes())
+    hb[128:128 + 25] = digest
+    gates = blob[256:256 + 48 * ng].tobytes()
+    capb = b"".join(cap[25 * i:25 * (i + 1)] + bytes(7) for i in range(1 << cap_h))
+    k_is = blob[256 + 48 * ng:256 + 48 * ng + 8 * R].tobytes()
+    return bytes(hb) + gates + capb + k_is
+
+
+def make(pkg, orc, d, mix, seed, npi=0, num_wires=234):
+    out = pkg.make_circuit(d, mix, seed, num_public_inputs=npi, num_wires=num_wires)
+    blob, wires = out[0], out[1]
+    pis = out[2] if npi else ()
+    oc = orc.OracleCircuit(blob)
+    vd = pkg.VerifierCircuitData(vk_blob(blob, oc.cap(), oc.digest()))
+    return oc, vd, wires, pis
+
+
+@pytest.mark.parametrize("d,mix,seed,npi,nw", [
+    (5, "arith", 1, 0, 234),    # no FRI reduction step: final polynomial of 2^5 coefficients
+    (6, "sha", 2, 0, 234),
+    (8, "ecdsa", 3, 0, 234),
+    (9, "ecdsa", 4, 4, 234),    # public inputs: PoseidonGate + PublicInputGate
+    (7, "arith", 5, 1, 135),    # standard_recursion_config width
+    (10, "sha", 6, 0, 234),     # two reduction steps
+])
+def test_accepts_oracle_proofs(pkg, orc, d, mix, seed, npi, nw):
+    oc, vd, wires, pis = make(pkg, orc, d, mix, seed, npi, nw)
+    proof, _ = oc.prove(wires, public_inputs=pis)
+    assert oc.verify(proof)
+    vd.verify(proof)  # raises when rejected
+    assert vd.circuit_digest() == oc.digest() and vd.constants_sigmas_cap() == oc.cap()
+    assert vd.num_public_inputs == npi and vd.degree_bits == d
+
+
+def test_rejects_what_the_oracle_rejects(pkg, orc):
+    """Flip one bit anywhere: caps, openings, fold caps, query rows, Merkle paths, final
+    polynomial, PoW witness, public inputs.  Both verifiers must say no, every time."""
+    oc, vd, wires, pis = make(pkg, orc, 8, "ecdsa", 7, npi=2)
+    proof, _ = oc.prove(wires, public_inputs=pis)
+    vd.verify(proof)
+    rng = np.random.default_rng(5)
+    n = len(proof)
+    fixed = [0, 24, 25 * 16, 3 * 25 * 16, 3 * 25 * 16 + 8, n - 1, n - 8, n - 16, n - 17, n - 24, n - 25]
+    positions = fixed + [int(x) for x in rng.integers(0, n, size=150)]
+    reasons = set()
+    for pos in positions:
+        bad = bytearray(proof)
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        bad = bytes(bad)
+        assert not oc.verify(bad), pos
+        with pytest.raises(pkg.P2GpuError) as ei:
+            vd.verify(bad)
+        assert ei.value.code == -9, pos
+        reasons.add(re.sub(r"\d+", "#", str(ei.value).split("proof rejected: ")[1]))
+    assert len(reasons) >= 4, reasons  # the mutations reached several different checks
+    # wrong length
+    for bad in (proof[:-1], proof + b"\0", proof[:100], b""):
+        assert not oc.verify(bad) if bad else True
+        with pytest.raises(pkg.P2GpuError) as ei:
+            vd.verify(bad)
+        assert ei.value.code in (-9, -7)
+
+
+def test_rejects_proof_of_unsatisfied_witness(pkg, orc):
+    """A witness that breaks a gate constraint or a copy constraint still yields proof bytes from
+    the oracle's prover (upstream's prover does not check either); no verifier may accept them."""
+    oc, vd, wires, _ = make(pkg, orc, 7, "ecdsa", 9)
+    for (col, row) in ((3, 5), (0, 2), (100, 40)):
+        bad = wires.copy()
+        bad[col, row] = (int(bad[col, row]) + 1) % P
+        proof, _ = oc.prove(bad)
+        assert not oc.verify(proof)
+        with pytest.raises(pkg.P2GpuError) as ei:
+            vd.verify(proof)
+        assert ei.value.code == -9 and "vanishing" in str(ei.value)
+
+
+def test_rejects_proof_for_another_circuit(pkg, orc):
+    oc1, vd1, w1, _ = make(pkg, orc, 6, "sha", 2)
+    oc2, vd2, w2, _ = make(pkg, orc, 6, "sha", 3)
+    p1, _ = oc1.prove(w1)
+    vd1.verify(p1)
+    with pytest.raises(pkg.P2GpuError):
+        vd2.verify(p1)
+
+
+def test_verifier_handle_has_no_prover(pkg, orc):
+    """A verifier-only handle holds no device state: the prove entry points refuse it (and the
+    refusal is not a fallback to some CPU prover)."""
+    import ctypes
+
+    oc, vd, wires, _ = make(pkg, orc, 5, "arith", 1)
+    lib = pkg.load_library()
+    out = np.zeros(1 << 20, dtype=np.uint8)
+    plen = ctypes.c_size_t(out.nbytes)
+    w = np.ascontiguousarray(wires)
+    rc = lib.p2gpu_prove(vd._h, w.ctypes.data, None, 0, out.ctypes.data, ctypes.byref(plen), None)
+    assert rc == -7 and b"verifier-only" in lib.p2gpu_last_error()
+    rc = lib.p2gpu_prove_routed(vd._h, w.ctypes.data, None, 0, out.ctypes.data, ctypes.byref(plen), None)
+    assert rc == -7
+    assert lib.p2gpu_circuit_set(vd._h, b"profile", 1) == -7
+
+
+def test_verifier_blob_validation(pkg, orc):
+    blob, wires = pkg.make_circuit(5, "arith", 1)
+    oc = orc.OracleCircuit(blob)
+    vk = vk_blob(blob, oc.cap(), oc.digest())
+    with pytest.raises(pkg.P2GpuError) as ei:  # a blob without cap/digest is not a verifier key
+        pkg.VerifierCircuitData(blob.tobytes())
+    assert ei.value.code == -1
+    with pytest.raises(pkg.P2GpuError):
+        pkg.VerifierCircuitData(vk[:-8])  # truncated k_is
+    with pytest.raises(pkg.P2GpuError):
+        pkg.VerifierCircuitData(b"\0" * 300)
+    # a tampered cap makes every proof fail at the first constants_sigmas Merkle path
+    proof, _ = oc.prove(wires)
+    ng = int(blob[:256].view(np.uint32)[23])
+    bad = bytearray(vk)
+    bad[256 + 48 * ng + 3] ^= 1
+    vd = pkg.VerifierCircuitData(bytes(bad))
+    with pytest.raises(pkg.P2GpuError) as ei:
+        vd.verify(proof)
+    assert "initial oracle 0" in str(ei.value)

@@ -25,8 +25,10 @@ namespace p2 {
 typedef uint64_t gl_t;
 constexpr uint64_t GL_P = 0xFFFFFFFF00000001ULL;
 constexpr uint64_t GL_EPS = 0xFFFFFFFFULL;
-constexpr uint64_t GL_GEN = 7;  // multiplicative generator = coset shift
-constexpr uint64_t GL_ROOT_2_32 = 1753635133440165772ULL;  // 7^((p-1)/2^32)
+// plonky2's generators (goldilocks_field.rs), not the "7 / 7^((p-1)/2^32)" pair other Goldilocks
+// libraries use: pinned by the reference's own proof artefacts (tests/golden/reference_proofs.py)
+constexpr uint64_t GL_GEN = 14293326489335486720ULL;  // MULTIPLICATIVE_GROUP_GENERATOR = coset shift
+constexpr uint64_t GL_ROOT_2_32 = 7277203076849721926ULL;   // POWER_OF_TWO_GENERATOR = GL_GEN^((p-1)/2^32); w_64 = 8
 
 P2_HD gl_t gl_canon(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
 P2_HD gl_t gl_add(gl_t a, gl_t b) {

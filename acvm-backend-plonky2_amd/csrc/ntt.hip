@@ -18,7 +18,7 @@
 // four: a lane holds 16 elements in registers, multiplies them by 15 per-group
 // twiddles (one coalesced load each from a table packed per round -- no index
 // arithmetic, no scattered root-table gathers) and then runs a 16-point DFT whose
-// internal twiddles are powers of w_16 = 2^156 = -2^60, i.e. shifts (2 is a 192nd
+// internal twiddles are powers of w_16 = 2^12, i.e. shifts (2 is a 192nd
 // root of unity in Goldilocks): 15 general modmuls per 16 elements per four
 // layers instead of 32.  This kernel is integer-ALU bound on gfx950 (a 64x64
 // modmul is ~29 VALU); the HBM traffic equals the algorithmic bytes.  No MFMA.
@@ -57,9 +57,9 @@ __device__ __forceinline__ gl_t mul_pow2(gl_t x) {
   }
 }
 
-// exponent of 2 for the constant twiddle w_{2^(lam+1)}^q (w_64 = 2^39), mod 192
+// exponent of 2 for the constant twiddle w_{2^(lam+1)}^q (w_64 = 2^3), mod 192
 __host__ __device__ constexpr int tw_exp(int lam, int q, bool inv) {
-  int e = (39 * (32 >> lam) * q) % 192;
+  int e = (3 * (32 >> lam) * q) % 192;
   return inv ? (192 - e) % 192 : e;
 }
 __host__ __device__ constexpr int brev_c(int x, int bits) {

@@ -1095,9 +1095,9 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
       dig_to_elems(dg, e);
       parts.insert(parts.end(), e, e + 4);
     }
-    std::vector<gl_t> pad(12, 0);
+    std::vector<gl_t> pad(8, 0);  // hash_pad([]): pad10*1 to the sponge rate
     pad[0] = 1;
-    pad[11] = 1;
+    pad[7] = 1;
     dig_t ds = host_hash_no_pad(pad);
     gl_t e[4];
     dig_to_elems(ds, e);

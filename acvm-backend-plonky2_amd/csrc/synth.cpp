@@ -434,6 +434,11 @@ int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint32_t num_pi, ui
         if (num_pi) b.connect(Cell{(uint32_t)r, i}, Cell{1 + nperm, 12 + i});
         else b.connect(Cell{(uint32_t)r, i}, Cell{1, 0});  // hash of no public inputs = constant zero
       }
+      // circuit_builder.rs randomize_unused_pi_wires: build() hangs a RandomValueGenerator on every
+      // other wire of this row (visible in the reference's own proofs, tests/golden/reference_proofs.py).
+      // Only the routed ones are randomised here, so that the row-local generators (N1) still
+      // reproduce the full matrix from the routed columns.
+      for (uint32_t i = 4; i < R; i++) b.w((uint32_t)r, i) = b.rng.field();
     } else {
       fill_row(b, g, (uint32_t)r, lc);
     }
@@ -445,7 +450,9 @@ int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint32_t num_pi, ui
   if (pis_out)
     for (uint32_t i = 0; i < num_pi; i++) pis_out[i] = pis[i];
 
-  // plonk/permutation_argument.rs: sigma maps each routed cell to the next cell of its partition class
+  // plonk/permutation_argument.rs: sigma maps each routed cell to the next cell of its partition
+  // class; WirePartition lists a class row by row (wire_partition(): `for row.. for column..`), which
+  // is the cycle order the reference's own proofs show (tests/golden/reference_proofs.py)
   std::vector<gl_t> k_is(R);
   k_is[0] = 1;
   for (uint32_t j = 1; j < R; j++) k_is[j] = gl_mul(k_is[j - 1], GL_GEN);
@@ -460,12 +467,14 @@ int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint32_t num_pi, ui
     size_t tot = (size_t)R * n;
     std::vector<uint32_t> root(tot), next(tot), last(tot, UINT32_MAX), first(tot, UINT32_MAX);
     for (size_t x = 0; x < tot; x++) root[x] = b.find((uint32_t)x);
-    for (size_t x = 0; x < tot; x++) {
-      uint32_t rt = root[x];
-      if (first[rt] == UINT32_MAX) first[rt] = (uint32_t)x;
-      else next[last[rt]] = (uint32_t)x;
-      last[rt] = (uint32_t)x;
-    }
+    for (size_t row = 0; row < n; row++)
+      for (uint32_t col = 0; col < R; col++) {
+        const size_t x = (size_t)col * n + row;
+        uint32_t rt = root[x];
+        if (first[rt] == UINT32_MAX) first[rt] = (uint32_t)x;
+        else next[last[rt]] = (uint32_t)x;
+        last[rt] = (uint32_t)x;
+      }
     for (size_t x = 0; x < tot; x++)
       if (last[root[x]] == x) next[x] = first[root[x]];
     for (size_t x = 0; x < tot; x++) {

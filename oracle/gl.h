@@ -24,9 +24,9 @@ typedef unsigned __int128 u128;
 
 #define GL_P 0xFFFFFFFF00000001ULL
 #define GL_EPS 0xFFFFFFFFULL /* 2^64 mod p */
-#define GL_GENERATOR 7ULL /* MULTIPLICATIVE_GROUP_GENERATOR, also coset shift */
+#define GL_GENERATOR 14293326489335486720ULL /* MULTIPLICATIVE_GROUP_GENERATOR, also coset shift */
 #define GL_TWO_ADICITY 32
-#define GL_POWER_OF_TWO_GENERATOR 1753635133440165772ULL /* 7^((p-1)/2^32) */
+#define GL_POWER_OF_TWO_GENERATOR 7277203076849721926ULL /* GL_GENERATOR^((p-1)/2^32); w_64 = 8 */
 #define GL_EXT_W 7ULL
 
 static inline gl_t gl_canon(uint64_t x) { return x >= GL_P ? x - GL_P : x; }

@@ -14,6 +14,8 @@ import __graft_entry__ as entry  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 P = 0xFFFFFFFF00000001
+GEN = 14293326489335486720      # plonky2 GoldilocksField::MULTIPLICATIVE_GROUP_GENERATOR (coset shift)
+ROOT32 = 7277203076849721926     # POWER_OF_TWO_GENERATOR = GEN^((p-1)/2^32)
 
 
 def pytest_configure(config):

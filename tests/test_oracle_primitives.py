@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, P
+from conftest import GEN, GOLDEN, P, ROOT32
 
 
 def test_field_modulus_and_generators(orc):
@@ -20,13 +20,15 @@ def test_field_modulus_and_generators(orc):
     assert P == 18446744069414584321 == 2**64 - 2**32 + 1
     L = orc.lib()
     assert L.orc_gl_mul(P - 1, P - 1) == 1
-    # POWER_OF_TWO_GENERATOR = 7^((p-1)/2^32), of order exactly 2^32
-    g = L.orc_gl_pow(7, (P - 1) >> 32)
-    assert g == 1753635133440165772
+    # plonky2's MULTIPLICATIVE_GROUP_GENERATOR / POWER_OF_TWO_GENERATOR (the pair the reference's own
+    # proof artefacts are consistent with, tests/test_reference_proofs.py -- NOT 7 / 7^((p-1)/2^32))
+    g = L.orc_gl_pow(GEN, (P - 1) >> 32)
+    assert g == ROOT32 == 7277203076849721926
     assert L.orc_gl_pow(g, 1 << 31) == P - 1 and L.orc_gl_pow(g, 1 << 32) == 1
-    # 7 generates the multiplicative group: 7^((p-1)/q) != 1 for every prime q | p-1
+    assert L.orc_gl_pow(g, 1 << 26) == 8   # w_64 = 8: the radix-64 twiddles are shifts
+    # GEN generates the multiplicative group: GEN^((p-1)/q) != 1 for every prime q | p-1
     for q in (2, 3, 5, 17, 257, 65537):
-        assert L.orc_gl_pow(7, (P - 1) // q) != 1
+        assert L.orc_gl_pow(GEN, (P - 1) // q) != 1
     for a in (1, 2, 7, 0xFFFFFFFF, 0xFFFFFFFF00000000, 1234567891011121314 % P):
         assert L.orc_gl_mul(a, L.orc_gl_inv(a)) == 1
     rng = np.random.default_rng(5)
@@ -165,7 +167,7 @@ def _py_dft(a, w):
 def test_ntt_matches_naive_dft(orc, lg):
     rng = np.random.default_rng(lg)
     a = rng.integers(0, P, size=1 << lg, dtype=np.uint64)
-    w = pow(1753635133440165772, 1 << (32 - lg), P)
+    w = pow(ROOT32, 1 << (32 - lg), P)
     assert [int(x) for x in orc.ntt(a)] == _py_dft([int(x) for x in a], w)
     assert np.array_equal(orc.ntt(orc.ntt(a), inverse=True), a)
 
@@ -175,9 +177,9 @@ def test_coset_lde_evaluates_the_polynomial(orc):
     d = 4
     c = rng.integers(0, P, size=1 << d, dtype=np.uint64)
     lde = orc.coset_lde(c, 3)
-    wN = pow(1753635133440165772, 1 << (32 - d - 3), P)
+    wN = pow(ROOT32, 1 << (32 - d - 3), P)
     for i in (0, 1, 7, 8, 100, 127):
-        x = 7 * pow(wN, i, P) % P
+        x = GEN * pow(wN, i, P) % P
         assert int(lde[i]) == sum(int(c[j]) * pow(x, j, P) for j in range(1 << d)) % P
 
 

@@ -140,7 +140,8 @@ def test_verifier_blob_validation(pkg, orc):
     proof, _ = oc.prove(wires)
     ng = int(blob[:256].view(np.uint32)[23])
     bad = bytearray(vk)
-    bad[256 + 48 * ng + 3] ^= 1
+    for i in range(16):  # every cap entry: whichever subtree the first query falls into
+        bad[256 + 48 * ng + 32 * i + 3] ^= 1
     vd = pkg.VerifierCircuitData(bytes(bad))
     with pytest.raises(pkg.P2GpuError) as ei:
         vd.verify(proof)

@@ -95,7 +95,7 @@ struct QuotArgs {
                                                 // cs_lde/qconst are indexed by r, wires/zp/out by z
   gl_t betas[MAX_CHALLENGES], gammas[MAX_CHALLENGES];
   gl_t pi_hash[4];
-  const gl_t *qconst;   // device [3][8]: coset shift 7 w_N^r | Z_H = 7^n w_8^r - 1 | 1 / Z_H
+  const gl_t *qconst;   // device [3][8]: coset shift g w_N^r | Z_H = g^n w_8^r - 1 | 1 / Z_H (g = GL_GEN)
                         // (in memory, not kernel arguments: they are indexed by blockIdx.y)
   gl_t n_inv;           // 1/n
 };

@@ -8,8 +8,8 @@
 // MI355X-first layout instead of plonky2's natural->natural transforms:
 //   * values -> coefficients is a DIF transform (natural in, BIT-REVERSED out);
 //     coefficients stay in bit-reversed positions for their whole life;
-//   * the 8x LDE on the coset 7<w_N> is 8 independent size-n DIT transforms
-//     (bit-reversed in, natural out) with coset shifts 7*w_N^r, r < 8; natural
+//   * the 8x LDE on the coset g<w_N> (g = GL_GEN) is 8 independent size-n DIT transforms
+//     (bit-reversed in, natural out) with coset shifts g*w_N^r, r < 8; natural
 //     LDE row i = 8k + r is output k of coset r.  No transpose, no bit-reversal
 //     pass and no zero-padded 8n-point FFT ever touches HBM.
 // A transform of 2^d points is split into passes of <= 12 layers; a pass stages a

@@ -1088,7 +1088,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
       if (memcmp(cap_in + 32 * i, c->cs.cap[i].w, 25)) return fail(P2GPU_E_CAP_MISMATCH, "constants_sigmas cap mismatch");
   }
   if (!(c->flags & 1)) {
-    // circuit_builder.rs build(): H::hash_no_pad(cap.flatten() || hash_pad([]).to_vec() || [degree_bits])  [P2-recall]
+    // circuit_builder.rs build(): H::hash_no_pad(cap.flatten() || hash_pad([]).to_vec() || [degree_bits])  (pinned: tests/test_reference_proofs.py)
     std::vector<gl_t> parts;
     for (auto &dg : c->cs.cap) {
       gl_t e[4];

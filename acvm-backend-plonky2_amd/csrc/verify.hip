@@ -12,7 +12,8 @@
 // verify_fri_proof):  shape of the byte string -> transcript replay -> plonk identity at zeta ->
 // proof-of-work -> per query: Merkle paths of the four initial oracles, the combined quotient
 // value, every arity-16 fold (closed-form barycentric interpolation on the coset s<g_16>), the
-// final polynomial.  Proof layout: SURVEY.md C.11 (flagged UNVERIFIED-VS-UPSTREAM there).
+// final polynomial.  Proof layout: SURVEY.md C.11; it accepts the reference's own proofs
+// (tests/test_reference_proofs.py::test_product_verifier_accepts_reference_proof).
 #include "circuit.hpp"
 #include <cstdarg>
 #include <cstdio>
@@ -381,7 +382,7 @@ int p2gpu_verify(const p2gpu_circuit *c, const uint8_t *proof, size_t len) {
         return reject("query %u: Merkle path of initial oracle %d does not lead to its cap", qi, o);
       t += oracle_cols[o];
     }
-    // the queried point: leaf x0 holds natural LDE row bitrev(x0), i.e. 7 w_N^bitrev(x0)
+    // the queried point: leaf x0 holds natural LDE row bitrev(x0), i.e. g w_N^bitrev(x0), g = GL_GEN
     size_t e = 0;
     for (unsigned b = 0; b < lgN; b++) e |= ((x0 >> b) & 1) << (lgN - 1 - b);
     unsigned lg = lgN;

@@ -165,7 +165,7 @@ int p2gpu_circuit_set_shard(p2gpu_circuit *c, int rank, int world, p2gpu_allgath
 /* stage-level operators (host buffers in/out; used by the parity tests) */
 /* values [ncols][2^d] -> coefficients [ncols][2^d], natural order */
 int p2gpu_ifft_batch(const uint64_t *vals, size_t ncols, unsigned d, uint64_t *coeffs_out);
-/* coefficients [ncols][2^d] -> LDE values [ncols][2^(d+rate_bits)] on the coset 7<w>, natural order */
+/* coefficients [ncols][2^d] -> LDE values [ncols][2^(d+rate_bits)] on the coset g<w> (g = 14293326489335486720, plonky2's coset shift), natural order */
 int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned rate_bits, uint64_t *lde_out);
 /* PolynomialBatch::from_values: commit value columns, return the Merkle cap (2^cap_h x 25 B) */
 int p2gpu_commit_values(const uint64_t *vals, size_t ncols, unsigned d, unsigned rate_bits, unsigned cap_h,

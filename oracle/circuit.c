@@ -193,7 +193,7 @@ int circuit_load(circuit_t *c, const uint8_t *blob, size_t len) {
     memcpy(c->circuit_digest.b, c->digest_in, DIGEST_BYTES);
   } else {
     /* circuit_builder.rs build(): circuit_digest = H::hash_no_pad(cap.flatten() ||
-     * hash_pad(domain_separator = []) .to_vec() || [degree_bits])   [P2-recall] */
+     * hash_pad(domain_separator = []) .to_vec() || [degree_bits])   (pad to the sponge RATE; pinned by tests/test_reference_proofs.py) */
     size_t ncap = (size_t)1 << c->cap_height;
     gl_t *parts = (gl_t *)malloc(sizeof(gl_t) * (4 * ncap + 5));
     for (size_t i = 0; i < ncap; i++) digest_to_elems(&c->cs.tree.cap[i], parts + 4 * i);

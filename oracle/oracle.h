@@ -9,15 +9,17 @@
  * Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may
  * load this library; the product (libp2gpu.so) never does.
  *
- * PARITY STATUS: "parity unpinned" at the proof-byte level.  plonky2 0.2.2
- * (fork github.com/brweisz/plonky2, unpinned path dependency:
+ * PARITY STATUS: pinned, bit-exact, to the two proofs the reference ships
+ * (plonky2-backend/example_programs/basic_{if,div}/proofs/*.proof; fixtures
+ * tests/golden/reference/, derivation tests/golden/reference_proofs.py):
+ * orc_prove reproduces their bytes from the circuit + witness recovered from
+ * them, orc_verify accepts them (tests/test_reference_proofs.py).  plonky2
+ * 0.2.2 itself (fork github.com/brweisz/plonky2, unpinned path dependency:
  * plonky2-backend/Cargo.toml:14,29-32, Cargo.lock:898-965) is not vendored
- * under /root/reference, no Rust toolchain exists in the image, and none of
- * the reference's tests pins proof bytes.  What IS
- * pinned (tests/test_oracle_*.py): Goldilocks constants, Keccak-256 KATs,
- * Poseidon round constants + permutation KAT, the custom gates' satisfying
- * assignments from the reference's own gate tests, and self-consistency
- * through the verifier restated here.
+ * under /root/reference and there is no Rust toolchain, so what those two
+ * 2^3-row proofs cannot reach stays pinned only to the reference's in-tree
+ * sources/tests: FRI reduction steps (arity-16 fold), RandomAccessGate and the
+ * five custom gates (tests/test_oracle_gates.py restates their gate tests).
  */
 #ifndef ORACLE_H
 #define ORACLE_H

@@ -7,9 +7,11 @@
  *   `circuit_data.prove(witnesses).unwrap()`
  * (test harness twin: circuit_translation/tests/factories/utils.rs:26).
  * The algorithm itself lives in the un-vendored plonky2 crate; this file
- * follows SURVEY.md Appendix C ([P2-recall], UNVERIFIED-VS-UPSTREAM):
+ * follows SURVEY.md Appendix C:
  *   C.4 transcript order, C.5 permutation argument, C.7 vanishing polynomial,
- *   C.8 openings, C.9 FRI batching + commit phase, C.10 PoW, C.11 bytes.
+ *   C.8 openings, C.9 FRI batching + commit phase, C.10 PoW, C.11 bytes
+ * -- all of it except the FRI reduction steps now verified byte for byte
+ * against the reference's own proofs (tests/test_reference_proofs.py).
  */
 #include "oracle.h"
 #include "circuit.h"

@@ -10,7 +10,7 @@
  * load this library; the product (libp2gpu.so) never does.
  *
  * PARITY STATUS: pinned, bit-exact, to the two proofs the reference ships
- * (plonky2-backend/example_programs/basic_{if,div}/proofs/*.proof; fixtures
+ * (plonky2-backend/example_programs/basic_{if,div}/proofs/basic_{if,div}.proof; fixtures
  * tests/golden/reference/, derivation tests/golden/reference_proofs.py):
  * orc_prove reproduces their bytes from the circuit + witness recovered from
  * them, orc_verify accepts them (tests/test_reference_proofs.py).  plonky2

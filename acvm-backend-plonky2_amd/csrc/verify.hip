@@ -14,7 +14,7 @@
 // value, every arity-16 fold (closed-form barycentric interpolation on the coset s<g_16>), the
 // final polynomial.  Proof layout: SURVEY.md C.11; it accepts the reference's own proofs
 // (tests/test_reference_proofs.py::test_product_verifier_accepts_reference_proof).
-#include "circuit.hpp"
+#include "hostproof.hpp"
 #include <cstdarg>
 #include <cstdio>
 
@@ -88,110 +88,6 @@ bool plonk_identity_holds(const p2gpu_circuit *c, const std::vector<ext_t> &op, 
 }  // namespace p2
 
 namespace {
-
-// bounds-checked cursor over the proof bytes
-struct Cursor {
-  const uint8_t *p;
-  size_t len, at = 0;
-  bool ok = true;
-  const uint8_t *take(size_t n) {
-    if (!ok || n > len - at) {
-      ok = false;
-      return nullptr;
-    }
-    const uint8_t *q = p + at;
-    at += n;
-    return q;
-  }
-  uint64_t u64() {
-    uint64_t v = 0;
-    if (const uint8_t *q = take(8)) memcpy(&v, q, 8);
-    return v;
-  }
-  gl_t felt() {  // canonical field element
-    uint64_t v = u64();
-    if (v >= GL_P) ok = false;
-    return v;
-  }
-  ext_t ext() {
-    gl_t a = felt(), b = felt();
-    return ext_make(a, b);
-  }
-  dig_t digest() {
-    dig_t d;
-    memset(&d, 0, sizeof d);
-    if (const uint8_t *q = take(25)) memcpy(d.w, q, 25);
-    return d;
-  }
-  void digests(std::vector<dig_t> &v, size_t n) {
-    v.resize(n);
-    for (auto &d : v) d = digest();
-  }
-};
-
-bool dig_eq(const dig_t &a, const dig_t &b) {
-  return a.w[0] == b.w[0] && a.w[1] == b.w[1] && a.w[2] == b.w[2] && (a.w[3] & 0xFF) == (b.w[3] & 0xFF);
-}
-
-// KeccakHash<25>::hash_or_noop of a leaf of field elements
-dig_t leaf_digest(const gl_t *v, size_t n) {
-  if (n * 8 <= 25) {
-    dig_t d;
-    memset(&d, 0, sizeof d);
-    for (size_t i = 0; i < n; i++) d.w[i] = v[i];
-    return d;
-  }
-  uint64_t h[4];
-  keccak256_words(v, n, h);
-  return dig_from_state(h);
-}
-
-// hash/merkle_proofs.rs verify_merkle_proof_to_cap
-bool merkle_path_ok(const gl_t *leaf, size_t n, size_t index, const std::vector<dig_t> &siblings,
-                    const std::vector<dig_t> &cap) {
-  dig_t cur = leaf_digest(leaf, n);
-  for (const dig_t &s : siblings) {
-    cur = (index & 1) ? keccak_two_to_one(s, cur) : keccak_two_to_one(cur, s);
-    index >>= 1;
-  }
-  return index < cap.size() && dig_eq(cur, cap[index]);
-}
-
-// sum_j alpha^j v_j
-template <class It>
-ext_t reduce_with_powers(It first, It last, ext_t alpha) {
-  ext_t acc = ext_from(0);
-  while (last != first) {
-    --last;
-    acc = ext_add(ext_mul(acc, alpha), *last);
-  }
-  return acc;
-}
-
-// Value at beta of the degree < a interpolant through (s g^j, y_j), j < a = 2^ab, g of order a.
-// The nodes are the roots of X^a - s^a, so the barycentric weights are x_j / (a s^a):
-//   P(beta) = (beta^a - s^a) / (a s^a) * sum_j y_j x_j / (beta - x_j).
-// (fri/verifier.rs compute_evaluation does the same interpolation with a generic routine.)
-ext_t interpolate_coset(gl_t s, unsigned ab, const ext_t *y_natural, ext_t beta) {
-  const uint32_t a = 1u << ab;
-  const gl_t g = gl_root(ab);
-  gl_t sa = s;
-  ext_t ba = beta;
-  for (unsigned i = 0; i < ab; i++) {
-    sa = gl_sqr(sa);
-    ba = ext_mul(ba, ba);
-  }
-  ext_t acc = ext_from(0);
-  gl_t x = s;
-  for (uint32_t j = 0; j < a; j++) {
-    const ext_t diff = ext_sub(beta, ext_from(x));
-    if (diff.c0 == 0 && diff.c1 == 0) return y_natural[j];
-    acc = ext_add(acc, ext_mul(ext_scale(y_natural[j], x), ext_inv(diff)));
-    x = gl_mul(x, g);
-  }
-  const gl_t scale = gl_inv(gl_mul((gl_t)a, sa));
-  return ext_mul(ext_scale(ext_sub(ba, ext_from(sa)), scale), acc);
-}
 
 int reject(const char *fmt, ...) {
   char buf[400];

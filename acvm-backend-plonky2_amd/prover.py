@@ -90,6 +90,9 @@ def load_library():
     lib.p2gpu_verify.argtypes = [vp, u8p, sz]
     lib.p2gpu_circuit_export_vk.argtypes = [vp, u8p, ctypes.POINTER(sz)]
     lib.p2gpu_verifier_create.argtypes = [u8p, sz, ctypes.POINTER(vp)]
+    lib.p2gpu_proof_compress.argtypes = [vp, u8p, sz, u8p, ctypes.POINTER(sz)]
+    lib.p2gpu_proof_decompress.argtypes = [vp, u8p, sz, u8p, ctypes.POINTER(sz)]
+    lib.p2gpu_verify_compressed.argtypes = [vp, u8p, sz]
     lib.p2gpu_circuit_set.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64]
     lib.p2gpu_circuit_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int, _ALLGATHER_FN, vp]
     lib.p2gpu_kernel_stats.argtypes = [vp, ctypes.c_char_p, vp, vp, vp, ctypes.c_int]
@@ -302,7 +305,38 @@ def _verify(lib, handle, proof):
     _check(lib.p2gpu_verify(handle, buf.ctypes.data if buf.size else None, buf.size))
 
 
-class VerifierCircuitData:
+def _convert(fn, handle, data):
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    n = ctypes.c_size_t(0)
+    _check(fn(handle, buf.ctypes.data if buf.size else None, buf.size, None, ctypes.byref(n)))
+    out = np.zeros(max(n.value, 1), dtype=np.uint8)
+    _check(fn(handle, buf.ctypes.data if buf.size else None, buf.size, out.ctypes.data, ctypes.byref(n)))
+    return out[:n.value].tobytes()
+
+
+class _ProofFormats:
+    """`proof.compress(..)` / `.decompress(..)` / `verify_compressed` of the reference's prove and
+    verify actions (prove_action.rs:75-78, verify_action.rs:11-17), on either kind of handle."""
+
+    def compress(self, proof):
+        data = proof.to_bytes() if hasattr(proof, "to_bytes") else bytes(proof)
+        return _convert(self._lib.p2gpu_proof_compress, self._h, data)
+
+    def decompress(self, compressed):
+        return ProofWithPublicInputs(_convert(self._lib.p2gpu_proof_decompress, self._h, compressed))
+
+    def verify_compressed(self, compressed):
+        buf = np.frombuffer(bytes(compressed), dtype=np.uint8)
+        _check(self._lib.p2gpu_verify_compressed(self._h, buf.ctypes.data if buf.size else None, buf.size))
+
+
+# the prover handle offers the same three conversions
+CircuitData.compress = _ProofFormats.compress
+CircuitData.decompress = _ProofFormats.decompress
+CircuitData.verify_compressed = _ProofFormats.verify_compressed
+
+
+class VerifierCircuitData(_ProofFormats):
     """Verifier-only handle (``VerifierCircuitData`` of the reference's verify action,
     plonky2-backend/src/actions/verify_action.rs:11-17).  Host code only: works without a GPU."""
 

@@ -2,6 +2,7 @@
  * p2gpu-prove -- stand-alone caller of the C ABI (include/p2gpu.h), plain C, no Python:
  *
  *     p2gpu-prove <circuit.blob> <wires.bin> <proof.bin> [public_inputs.bin] [--routed] [--vk <vk.blob>]
+ *                 [--reference-format]
  *
  * The counterpart of `plonky2-backend prove -b <acir> -w <witness> -o <proof>`
  * (plonky2-backend/src/argument_parsing.rs:36-41 -> actions/prove_action.rs:27-43) below the
@@ -9,7 +10,9 @@
  * wires.bin is the dense witness matrix [num_wires][n] of little-endian u64 (with --routed only
  * the [num_routed_wires][n] routed columns; the rest is derived on the GPU).  Writes the
  * uncompressed ProofWithPublicInputs bytes; --vk also writes the verifier's share of the circuit for
- * p2gpu-verify (the reference's `write_vk`, actions/write_vk_action.rs:65-81).  Exit code 0 = ok, 1 = usage/IO, 2 = library error.
+ * p2gpu-verify (the reference's `write_vk`, actions/write_vk_action.rs:65-81); --reference-format
+ * writes what the reference's CLI writes instead: hex text of the COMPRESSED proof
+ * (prove_action.rs:38-42,75-78).  Exit code 0 = ok, 1 = usage/IO, 2 = library error.
  */
 #include "../../include/p2gpu.h"
 #include <stdio.h>
@@ -33,15 +36,16 @@ static void *slurp(const char *path, size_t *len) {
 }
 
 int main(int argc, char **argv) {
-  int routed = 0, npos = 0;
+  int routed = 0, npos = 0, ref_format = 0;
   const char *pos[4] = {0, 0, 0, 0}, *vk_path = NULL;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--routed")) routed = 1;
+    else if (!strcmp(argv[i], "--reference-format")) ref_format = 1;
     else if (!strcmp(argv[i], "--vk") && i + 1 < argc) vk_path = argv[++i];
     else if (npos < 4) pos[npos++] = argv[i];
   }
   if (npos < 3) {
-    fprintf(stderr, "usage: %s <circuit.blob> <wires.bin> <proof.bin> [public_inputs.bin] [--routed] [--vk <vk.blob>]\n", argv[0]);
+    fprintf(stderr, "usage: %s <circuit.blob> <wires.bin> <proof.bin> [public_inputs.bin] [--routed] [--vk <vk.blob>] [--reference-format]\n", argv[0]);
     return 1;
   }
   size_t blob_len, wires_len, pi_len = 0;
@@ -81,7 +85,23 @@ int main(int argc, char **argv) {
     return 2;
   }
   FILE *f = fopen(pos[2], "wb");
-  if (!f || fwrite(proof, 1, len, f) != len) {
+  if (!f) {
+    fprintf(stderr, "cannot write %s\n", pos[2]);
+    return 1;
+  }
+  if (ref_format) {
+    size_t clen = 0;
+    p2gpu_proof_compress(c, proof, len, NULL, &clen);
+    uint8_t *comp = malloc(clen ? clen : 1);
+    rc = p2gpu_proof_compress(c, proof, len, comp, &clen);
+    if (rc) {
+      fprintf(stderr, "p2gpu_proof_compress: %d: %s\n", rc, p2gpu_last_error());
+      return 2;
+    }
+    for (size_t i = 0; i < clen; i++) fprintf(f, "%02x", comp[i]);
+    fprintf(stderr, "compressed: %zu -> %zu bytes, written as hex\n", len, clen);
+    free(comp);
+  } else if (fwrite(proof, 1, len, f) != len) {
     fprintf(stderr, "cannot write %s\n", pos[2]);
     return 1;
   }

@@ -6,11 +6,15 @@
  * The counterpart of `plonky2-backend verify -k <vk> -p <proof>`
  * (plonky2-backend/src/argument_parsing.rs:49-53 -> actions/verify_action.rs:11-17) on the
  * uncompressed proof bytes p2gpu-prove writes.  <vk.blob> is the verifier's share of the circuit
- * (p2gpu_circuit_export_vk, or `p2gpu-prove --vk <file>`).  Exit code 0 = proof accepted,
+ * (p2gpu_circuit_export_vk, or `p2gpu-prove --vk <file>`).  A proof file that consists of hex digits
+ * only is taken to be in the reference's own format -- hex of the COMPRESSED proof
+ * (prove_action.rs:38-42,75-78) -- and goes through verify_compressed like verify_action.rs:14-16.
+ * Exit code 0 = proof accepted,
  * 1 = usage/IO, 2 = bad blob, 3 = proof rejected (the failed check is printed).
  */
 #include "../../include/p2gpu.h"
 #include <stdio.h>
+#include <ctype.h>
 #include <stdlib.h>
 
 static void *slurp(const char *path, size_t *len) {
@@ -47,7 +51,30 @@ int main(int argc, char **argv) {
     fprintf(stderr, "p2gpu_verifier_create: %d: %s\n", rc, p2gpu_last_error());
     return 2;
   }
-  rc = p2gpu_verify(c, proof, proof_len);
+  int is_hex = proof_len > 0;
+  size_t digits = 0;
+  for (size_t i = 0; i < proof_len && is_hex; i++) {
+    if (isxdigit(proof[i])) digits++;
+    else if (!isspace(proof[i])) is_hex = 0;
+  }
+  if (is_hex && digits % 2 == 0) {
+    uint8_t *bin = malloc(digits / 2 + 1);
+    size_t n = 0;
+    int hi = -1;
+    for (size_t i = 0; i < proof_len; i++) {
+      if (!isxdigit(proof[i])) continue;
+      int v = isdigit(proof[i]) ? proof[i] - '0' : (tolower(proof[i]) - 'a' + 10);
+      if (hi < 0) hi = v;
+      else {
+        bin[n++] = (uint8_t)(hi << 4 | v);
+        hi = -1;
+      }
+    }
+    rc = p2gpu_verify_compressed(c, bin, n);
+    free(bin);
+  } else {
+    rc = p2gpu_verify(c, proof, proof_len);
+  }
   if (rc) fprintf(stderr, "p2gpu_verify: %d: %s\n", rc, p2gpu_last_error());
   else fprintf(stderr, "proof accepted (%zu bytes)\n", proof_len);
   p2gpu_circuit_destroy(c);

@@ -140,6 +140,16 @@ int p2gpu_circuit_export_vk(const p2gpu_circuit *c, uint8_t *out, size_t *len);
  * No device is touched; the prove / fill / shard entry points reject it with P2GPU_E_ARG. */
 int p2gpu_verifier_create(const uint8_t *blob, size_t len, p2gpu_circuit **out);
 
+/* ---- the reference's on-disk proof format (host code only) ------------------------------------
+ * `plonky2-backend prove` writes hex(proof.compress(..).to_bytes()) (prove_action.rs:38-42,75-78) and
+ * `verify` reads it back with verify_compressed (verify_action.rs:11-17).  compress / decompress
+ * convert between p2gpu_prove's uncompressed bytes and that compressed layout (binary; hex is the
+ * caller's business); out == NULL: only report the size in *out_len.  decompress rebuilds what was
+ * dropped but does not judge the proof -- p2gpu_verify_compressed = decompress + p2gpu_verify. */
+int p2gpu_proof_compress(const p2gpu_circuit *c, const uint8_t *proof, size_t len, uint8_t *out, size_t *out_len);
+int p2gpu_proof_decompress(const p2gpu_circuit *c, const uint8_t *cproof, size_t len, uint8_t *out, size_t *out_len);
+int p2gpu_verify_compressed(const p2gpu_circuit *c, const uint8_t *cproof, size_t len);
+
 /* optional knobs: "pow_hint" (u64; UINT64_MAX = grind), "self_check" (0/1, default 1: evaluate the
  * verifier's plonk identity at zeta on the host before FRI and return P2GPU_E_UNSATISFIED when the
  * witness does not satisfy the circuit; 0 = emit the proof anyway like upstream), "profile" (0 / 1 / 2: time kernel

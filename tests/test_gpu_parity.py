@@ -235,6 +235,9 @@ def test_full_size_proof_is_accepted(pkg, orc, gpu, mix):
     ov = orc.OracleCircuit(blob, verifier_cap=cd.constants_sigmas_cap(), verifier_digest=cd.circuit_digest())
     assert ov.verify(proof.to_bytes())
     cd.verifier_data().verify(proof)
+    comp = cd.compress(proof)          # the reference's on-disk format
+    assert len(comp) < len(proof) and cd.decompress(comp).to_bytes() == proof.to_bytes()
+    cd.verify_compressed(comp)
     # reproducible, and a tampered opening is rejected
     assert cd.prove(wires).to_bytes() == proof.to_bytes()
     bad = bytearray(proof.to_bytes())
@@ -305,6 +308,14 @@ def test_standalone_c_caller(pkg, orc, gpu, tmp_path):
     (tmp_path / "bad.bin").write_bytes(bytes(tampered))
     r = subprocess.run([vexe, str(tmp_path / "vk.blob"), str(tmp_path / "bad.bin")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 3 and "rejected" in r.stderr
+    # --reference-format: hex of the compressed proof, the file format of the reference's CLI
+    cmd = [exe, str(tmp_path / "c.blob"), str(tmp_path / "w.bin"), str(tmp_path / "p.hex"), str(tmp_path / "pi.bin"), "--reference-format"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    hx = (tmp_path / "p.hex").read_text()
+    assert len(hx) // 2 < len(expect) and bytes.fromhex(hx)[:25] == expect[:25]
+    r = subprocess.run([vexe, str(tmp_path / "vk.blob"), str(tmp_path / "p.hex")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "accepted" in r.stderr, r.stderr
     # a broken blob is reported through the error code + message, not a crash
     (tmp_path / "bad.blob").write_bytes(b"\0" * 300)
     r = subprocess.run([exe, str(tmp_path / "bad.blob"), str(tmp_path / "w.bin"), str(tmp_path / "p3.bin")],

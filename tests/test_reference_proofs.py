@@ -144,3 +144,48 @@ def test_gpu_prover_reproduces_reference_proof(cases, pkg, name):
     cd.verify(c.uncompressed())
     cd.verifier_data().verify(c.uncompressed())
     cd.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_compressed_format_round_trips_the_reference_file(cases, orc, pkg, name):
+    """N3: the product's compress / decompress / verify_compressed on the reference's own file
+    (`proof.compress(..).to_bytes()`, prove_action.rs:75-78): decompress gives the bytes the
+    fixture module rebuilt independently, compress gives the file back, verify_compressed accepts."""
+    from test_verifier import vk_blob
+
+    c = cases[name]
+    blob = c.blob()
+    oc = orc.OracleCircuit(blob)
+    vd = pkg.VerifierCircuitData(vk_blob(blob, oc.cap(), oc.digest()))
+    assert vd.decompress(c.compressed).to_bytes() == c.uncompressed()
+    assert vd.compress(c.uncompressed()) == c.compressed
+    vd.verify_compressed(c.compressed)
+    bad = bytearray(c.compressed)
+    bad[len(bad) // 2] ^= 4
+    with pytest.raises(pkg.P2GpuError):
+        vd.verify_compressed(bytes(bad))
+    with pytest.raises(pkg.P2GpuError):
+        vd.verify_compressed(c.compressed[:-3])
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_verify_tool_accepts_the_reference_file_as_shipped(cases, orc, pkg, tmp_path, name):
+    """`p2gpu-verify <vk> <file>` on the reference's .proof file exactly as it lies in its tree
+    (hex text of the compressed proof): the plain-C counterpart of `plonky2-backend verify`."""
+    import subprocess
+
+    from conftest import ROOT
+    from test_verifier import vk_blob
+
+    c = cases[name]
+    blob = c.blob()
+    oc = orc.OracleCircuit(blob)
+    (tmp_path / "vk.blob").write_bytes(vk_blob(blob, oc.cap(), oc.digest()))
+    exe = os.path.join(ROOT, "acvm-backend-plonky2_amd", "p2gpu-verify")
+    src = os.path.join(GOLDEN, "reference", name + ".proof.hex")
+    r = subprocess.run([exe, str(tmp_path / "vk.blob"), src], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "accepted" in r.stderr, r.stderr
+    text = open(src).read()
+    (tmp_path / "bad.hex").write_text(text[:5000] + ("0" if text[5000] != "0" else "1") + text[5001:])
+    r = subprocess.run([exe, str(tmp_path / "vk.blob"), str(tmp_path / "bad.hex")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3, r.stderr

@@ -146,3 +146,29 @@ def test_verifier_blob_validation(pkg, orc):
     with pytest.raises(pkg.P2GpuError) as ei:
         vd.verify(proof)
     assert "initial oracle 0" in str(ei.value)
+
+
+@pytest.mark.parametrize("d,mix,seed,npi", [(5, "arith", 1, 0), (9, "ecdsa", 4, 4), (10, "sha", 6, 0), (11, "arith", 8, 1)])
+def test_compress_round_trip(pkg, orc, d, mix, seed, npi):
+    """The reference's on-disk format (compressed proof, prove_action.rs:75-78) with fold steps:
+    compress then decompress is the identity, the compressed proof is smaller and is accepted by
+    verify_compressed; queries that share a fold-step leaf (certain at these sizes: 28 queries into
+    2^(d+3-4) leaves and fewer) exercise the shared-entry / inferred-element logic."""
+    oc, vd, wires, pis = make(pkg, orc, d, mix, seed, npi)
+    proof, tr = oc.prove(wires, public_inputs=pis)
+    comp = vd.compress(proof)
+    assert len(comp) < len(proof)
+    assert vd.decompress(comp).to_bytes() == proof
+    vd.verify_compressed(comp)
+    # layout: indices sit right after caps | openings | fold caps
+    h = np.frombuffer(vd.to_bytes()[:256], dtype=np.uint32)
+    nsteps, nc, w = int(h[13]), int(h[5]), int(h[3])
+    at = 3 * 16 * 25 + 16 * (nc + 80 + w + 2 + 2 + 18 + 16) + nsteps * 16 * 25
+    assert list(np.frombuffer(comp[at:at + 4 * 28], dtype=np.uint32)) == [int(x) for x in tr.query_indices[:28]]
+    # any flipped bit is caught (by the decompressor or by the verifier behind it)
+    rng = np.random.default_rng(d)
+    for pos in [int(x) for x in rng.integers(0, len(comp), size=60)] + [at, at + 111]:
+        bad = bytearray(comp)
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        with pytest.raises(pkg.P2GpuError):
+            vd.verify_compressed(bytes(bad))

@@ -782,6 +782,15 @@ int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off
   c->C = 1u << c->rate_bits;
   c->nchunks = (c->R + c->QF - 1) / c->QF;
   if (c->nchunks > 16 || c->PP != c->nchunks - 1) return fail(P2GPU_E_BLOB, "unsupported circuit parameters");
+  {
+    // fri/reduction_strategies.rs: every step must leave at least the cap below it
+    uint32_t ds = c->d;
+    for (uint32_t s = 0; s < c->n_steps; s++) {
+      const uint32_t ab = c->arity[s];
+      if (ab < 1 || ab > 4 || ds < ab || ds + c->rate_bits - ab < c->cap_h) return fail(P2GPU_E_BLOB, "unsupported FRI reduction arity");
+      ds -= ab;
+    }
+  }
   size_t off = 256;
   if (len < off + (size_t)c->num_gates * 48) return fail(P2GPU_E_BLOB, "blob truncated (gate table)");
   c->max_gate_constraints = 0;

@@ -172,3 +172,23 @@ def test_compress_round_trip(pkg, orc, d, mix, seed, npi):
         bad[pos] ^= 1 << int(rng.integers(0, 8))
         with pytest.raises(pkg.P2GpuError):
             vd.verify_compressed(bytes(bad))
+
+
+def test_garbage_never_crashes_the_host_parsers(pkg, orc):
+    """The verifier and the (de)compressor read untrusted bytes: truncations, random tails and pure
+    noise must come back as error codes (the process surviving this test is the assertion)."""
+    oc, vd, wires, pis = make(pkg, orc, 9, "ecdsa", 4, 4)
+    proof, _ = oc.prove(wires, public_inputs=pis)
+    comp = vd.compress(proof)
+    rng = np.random.default_rng(11)
+    cases = []
+    for src in (proof, comp):
+        for cut in [int(x) for x in rng.integers(0, len(src), size=25)]:
+            cases.append(src[:cut])
+            cases.append(src[:cut] + rng.bytes(len(src) - cut))
+        cases.append(src + b"\0" * 7)
+    cases += [rng.bytes(n) for n in (0, 1, 24, 1200, len(comp), len(proof))]
+    for blob in cases:
+        for fn in (vd.verify, vd.verify_compressed, vd.decompress, vd.compress):
+            with pytest.raises(pkg.P2GpuError):
+                fn(blob)

@@ -775,7 +775,8 @@ int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off
   if (hasher != 0) return fail(P2GPU_E_BLOB, "unsupported hasher (only KeccakHash<25>)");
   if (c->d < 1 || c->d > 24 || c->K < 1 || c->K > 2 || c->rate_bits < 1 || c->rate_bits > 3 || c->cap_h < c->rate_bits ||
       c->cap_h > c->rate_bits + c->d || c->n_steps > 8 || c->R > MAX_ROUTED || c->QF == 0 || c->num_gates > MAX_GATES ||
-      c->num_queries > 64 || c->W < c->R || (1u << c->rate_bits) != c->QF || c->pow_bits > 32)
+      c->num_queries > 64 || c->W < c->R || (1u << c->rate_bits) != c->QF || c->pow_bits > 32 || c->W > 4096 ||
+      c->NC > 4096 || c->num_selectors > c->NC || c->num_selectors == 0 || c->num_pi > (1u << 20) || c->num_queries == 0)
     return fail(P2GPU_E_BLOB, "unsupported circuit parameters");
   c->n = (size_t)1 << c->d;
   c->N = c->n << c->rate_bits;

@@ -1,0 +1,35 @@
+"""Repeatability stress: many proofs on several handles from several threads must always give the
+same bytes (a missing stream/event dependency shows up here, not in single-shot tests)."""
+import sys, threading, hashlib
+import numpy as np
+sys.path.insert(0, "/root/repo")
+import __graft_entry__ as entry
+import torch
+pkg = entry.load_package()
+orc = entry.load_oracle()
+cases = [(9, "ecdsa", 1, 3), (12, "sha", 2, 0), (13, "ecdsa", 3, 0), (14, "arith", 4, 2)]
+ref = {}
+handles = []
+for d, mix, seed, npi in cases:
+    out = pkg.make_circuit(d, mix, seed, num_public_inputs=npi)
+    blob, wires = out[0], out[1]
+    pis = out[2] if npi else ()
+    expect, _ = orc.OracleCircuit(blob).prove(wires, public_inputs=pis)
+    for rep in range(2):
+        cd = pkg.CircuitData(blob)
+        handles.append((cd, wires, torch.from_numpy(wires.view(np.int64)).cuda(), pis, expect))
+bad = []
+def work(i, n):
+    cd, wh, wd, pis, expect = handles[i]
+    for it in range(n):
+        src = wd if it % 3 else wh          # device witness / host witness (chunked upload) / routed
+        if it % 7 == 5:
+            p = cd.prove_routed(wh[:80], public_inputs=pis).to_bytes()
+        else:
+            p = cd.prove(src, public_inputs=pis).to_bytes()
+        if p != expect:
+            bad.append((i, it, hashlib.sha256(p).hexdigest()[:12]))
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+th = [threading.Thread(target=work, args=(i, n)) for i in range(len(handles))]
+[t.start() for t in th]; [t.join() for t in th]
+print("proofs", n * len(handles), "mismatches", len(bad), bad[:5])

@@ -956,9 +956,16 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     return P2GPU_E_DEVICE;                            \
   }
   CK(hipSetDevice(c->device), "hipSetDevice");
+  const double t_create0 = now_ms();
+  auto mark = [&](const char *label) {  // P2GPU_TRACE=1: where circuit creation spends its time
+    if (!trace_on()) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    fprintf(stderr, "[p2gpu] create %-28s +%.2f ms\n", label, now_ms() - t_create0);
+  };
   if (poseidon_upload_constants()) return fail(P2GPU_E_DEVICE, "uploading Poseidon constants failed");
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
   CK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
+  mark("streams + poseidon constants");
   hipStream_t st = c->stream;
   const uint32_t d = c->d, K = c->K, C = c->C;
   const uint32_t ncs = c->NC + c->R, nzp = K * (1 + c->PP), nq = K * c->QF;
@@ -993,6 +1000,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     }
     CK(hipMemcpy(c->qconst.p, qc, sizeof qc, hipMemcpyHostToDevice), "copy qconst");
   }
+  mark("root tables + ntt plans");
   CK(hipMemcpyAsync(c->d_kis.p, k_is, 8 * (size_t)c->R, hipMemcpyHostToDevice, st), "copy kis");
   CK(hipMemcpyAsync(c->d_sigmas.p, sigmas, 8 * (size_t)c->R * n, hipMemcpyHostToDevice, st), "copy sigmas");
   if (c->num_gates)
@@ -1019,6 +1027,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
       CK(hipMemcpy(c->d_gconsts.p, constants + (size_t)c->num_selectors * n, 8 * (size_t)ngc * n, hipMemcpyHostToDevice), "copy gconsts");
     CK(hipMemcpy(c->d_prc.p, c->poseidon_rc, sizeof c->poseidon_rc, hipMemcpyHostToDevice), "copy prc");
   }
+  mark("sigma/constant uploads, row->gate");
   if (batch_alloc(c, c->cs, ncs) || batch_alloc(c, c->wires, c->W) || batch_alloc(c, c->zp, nzp) || batch_alloc(c, c->quot, nq)) {
     std::string keep = g_err;
     circuit_release(c);
@@ -1075,6 +1084,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   CK(c->gather_out.alloc(c->gather_cap), "alloc gather");
   CK(c->pow_result.alloc(1), "alloc pow");
 
+  mark("batch + work buffer allocation");
   // ---- constants_sigmas commitment (the prover-side part of `build()`) ----
   {
     // stage values [constants | sigmas] in the wires buffer region of the cs LDE (reuse cs.lde as scratch)
@@ -1116,6 +1126,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     c->circuit_digest = host_hash_no_pad(parts);
   }
   CK(hipStreamSynchronize(st), "sync");
+  mark("constants_sigmas commitment");
 #undef CK
   *out_c = c;
   return P2GPU_OK;

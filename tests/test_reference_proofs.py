@@ -233,3 +233,38 @@ def test_gpu_generators_rebuild_the_reference_witness(cases, pkg, name):
     keep = [r for r in range(1 << rp.D) if r != _pi_row(c)]
     assert np.array_equal(got[:, keep], c.wires[:, keep])
     cd.close()
+
+
+def _batch_values(c, tree):
+    """Values on the subgroup H of the columns of prover tree 1 (wires), 2 (Z + partial products) or
+    3 (quotient chunks), from the recovered coefficients."""
+    g = rp.root_of_unity(rp.D)
+    H = [pow(g, i, rp.P) for i in range(1 << rp.D)]
+    return np.array([[rp.poly_eval(col, h) for h in H] for col in c.polys[tree]], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_commitments_equal_the_reference_caps(cases, orc, name):
+    """Stage level: PolynomialBatch::from_values (iNTT -> 8x coset LDE -> Keccak tree) of the three
+    prover batches gives exactly the three Merkle caps in the reference's proof -- all 16 entries."""
+    c = cases[name]
+    for tree in (1, 2, 3):
+        cap = orc.commit_values(_batch_values(c, tree), rp.RATE_BITS, rp.CAP_H)
+        assert cap == b"".join(c.pr["caps"][tree - 1]), tree
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_commitments_equal_the_reference_caps(cases, pkg, name):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    c = cases[name]
+    for tree in (1, 2, 3):
+        vals = _batch_values(c, tree)
+        assert pkg.commit_values(vals, rp.RATE_BITS, rp.CAP_H) == b"".join(c.pr["caps"][tree - 1]), tree
+        # and the LDE itself: the opened rows of the reference proof
+        lde = pkg.lde_batch(pkg.ifft_batch(vals), rp.RATE_BITS)
+        for x in c.pr["indices"]:
+            assert [int(v) for v in lde[:, rp.bitrev(x, rp.D + rp.RATE_BITS)]] == c.pr["init"][x][tree][0]

@@ -49,16 +49,16 @@ struct ExtOps {
 };
 
 template <class F>
+P2_HD typename F::T range4(typename F::T v) {  // v (v-1) (v-2) (v-3) = u (u + 2), u = v^2 - 3v: two products
+  typename F::T u = F::sub(F::mul(v, v), F::add(F::dbl(v), v));
+  return F::mul(u, F::add(u, F::from(2)));
+}
+template <class F>
 P2_HD typename F::T range_product(typename F::T v, uint32_t base) {
+  if (base == 4) return range4<F>(v);
   typename F::T p = v;
   for (uint32_t x = 1; x < base; x++) p = F::mul(p, F::sub(v, F::from(x)));
   return p;
-}
-template <class F>
-P2_HD typename F::T range4(typename F::T v) {  // v (v-1) (v-2) (v-3)
-  typename F::T a = F::mul(v, F::sub(v, F::from(1)));
-  typename F::T b = F::mul(F::sub(v, F::from(2)), F::sub(v, F::from(3)));
-  return F::mul(a, b);
 }
 // RandomAccessGate list fold: the nested multiplexer x + b (y - x), lowest bit innermost (the
 // same expression tree as folding pairs level by level), evaluated depth-first with

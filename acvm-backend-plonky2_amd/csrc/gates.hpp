@@ -37,6 +37,18 @@ struct BaseOps {
   static P2_HD T mul(T a, T b) { return gl_mul(a, b); }
   static P2_HD T mul_small(T a, uint32_t k) { return gl_mul_small(a, k); }
   static P2_HD T dbl(T a) { return gl_dbl(a); }
+  // acc = acc * 2^bits + v, kept unreduced in 128 bits and reduced once: limb recompositions
+  // (sum_j limb_j 2^(bits j)) are chains of these.  The total shift must stay <= 63 bits.
+  struct Horner {
+    uint64_t lo = 0, hi = 0;
+    P2_HD void push(T v, uint32_t bits) {
+      hi = (hi << bits) | (lo >> (64 - bits));
+      lo <<= bits;
+      lo += v;
+      hi += lo < v;
+    }
+    P2_HD T value() const { return gl_reduce128(lo, hi); }
+  };
 };
 struct ExtOps {
   typedef ext_t T;
@@ -46,6 +58,11 @@ struct ExtOps {
   static P2_HD T mul(T a, T b) { return ext_mul(a, b); }
   static P2_HD T mul_small(T a, uint32_t k) { return ext_make(gl_mul_small(a.c0, k), gl_mul_small(a.c1, k)); }
   static P2_HD T dbl(T a) { return ext_add(a, a); }
+  struct Horner {
+    T acc = ext_make(0, 0);
+    P2_HD void push(T v, uint32_t bits) { acc = add(mul_small(acc, 1u << bits), v); }
+    P2_HD T value() const { return acc; }
+  };
 };
 
 template <class F>
@@ -104,10 +121,17 @@ P2_HD void eval_gate(const GateDesc &g, WF W, CF LC, const typename F::T *pih, c
   case G_BASE_SUM: {
     const uint32_t B = g.p[0], L = g.p[1];
     T acc = F::from(0);
+    const uint32_t lb = B == 2 ? 1 : (B == 4 ? 2 : 0);
+    if (lb && lb * L <= 63) {
+      typename F::Horner h;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 8
 #endif
-    for (uint32_t i = L; i-- > 0;) acc = F::add(F::mul_small(acc, B), W(1 + i));
+      for (uint32_t i = L; i-- > 0;) h.push(W(1 + i), lb);
+      acc = h.value();
+    } else {
+      for (uint32_t i = L; i-- > 0;) acc = F::add(F::mul_small(acc, B), W(1 + i));
+    }
     out.emit(F::sub(acc, W(0)));
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 8
@@ -231,18 +255,18 @@ P2_HD void eval_gate(const GateDesc &g, WF W, CF LC, const typename F::T *pih, c
       out.emit(F::mul(hi_not_max, lo));
       T combined = F::add(F::mul(hi, F::from(1ULL << 32)), lo);
       out.emit(F::sub(combined, computed));
-      T cl = F::from(0), ch = F::from(0);
+      typename F::Horner cl, ch;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 8
 #endif
       for (uint32_t j = 32; j-- > 0;) {
         T limb = W(6 * ops + 32 * i + j);
         out.emit(range4<F>(limb));
-        if (j < 16) cl = F::add(F::mul_small(cl, 4), limb);
-        else ch = F::add(F::mul_small(ch, 4), limb);
+        if (j < 16) cl.push(limb, 2);
+        else ch.push(limb, 2);
       }
-      out.emit(F::sub(cl, lo));
-      out.emit(F::sub(ch, hi));
+      out.emit(F::sub(cl.value(), lo));
+      out.emit(F::sub(ch.value(), hi));
     }
     break;
   }
@@ -255,18 +279,18 @@ P2_HD void eval_gate(const GateDesc &g, WF W, CF LC, const typename F::T *pih, c
       T res = W(b + na + 1), oc = W(b + na + 2);
       T combined = F::add(F::mul(oc, F::from(1ULL << 32)), res);
       out.emit(F::sub(combined, computed));
-      T cr = F::from(0), cc = F::from(0);
+      typename F::Horner cr, cc;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 6
 #endif
       for (uint32_t j = 18; j-- > 0;) {
         T limb = W((na + 3) * ops + 18 * i + j);
         out.emit(range4<F>(limb));
-        if (j < 16) cr = F::add(F::mul_small(cr, 4), limb);
-        else cc = F::add(F::mul_small(cc, 4), limb);
+        if (j < 16) cr.push(limb, 2);
+        else cc.push(limb, 2);
       }
-      out.emit(F::sub(cr, res));
-      out.emit(F::sub(cc, oc));
+      out.emit(F::sub(cr.value(), res));
+      out.emit(F::sub(cc.value(), oc));
     }
     break;
   }
@@ -276,16 +300,16 @@ P2_HD void eval_gate(const GateDesc &g, WF W, CF LC, const typename F::T *pih, c
       T x = W(5 * i), y = W(5 * i + 1), bin = W(5 * i + 2), res = W(5 * i + 3), bout = W(5 * i + 4);
       T init = F::sub(F::sub(x, y), bin);
       out.emit(F::sub(res, F::add(init, F::mul(bout, F::from(1ULL << 32)))));
-      T comb = F::from(0);
+      typename F::Horner comb;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 8
 #endif
       for (uint32_t j = 16; j-- > 0;) {
         T limb = W(5 * ops + 16 * i + j);
         out.emit(range4<F>(limb));
-        comb = F::add(F::mul_small(comb, 4), limb);
+        comb.push(limb, 2);
       }
-      out.emit(F::sub(comb, res));
+      out.emit(F::sub(comb.value(), res));
       out.emit(F::mul(bout, F::sub(F::from(1), bout)));
     }
     break;
@@ -293,12 +317,12 @@ P2_HD void eval_gate(const GateDesc &g, WF W, CF LC, const typename F::T *pih, c
   case G_U32_RANGE_CHECK: {
     const uint32_t nl = g.p[0];
     for (uint32_t i = 0; i < nl; i++) {
-      T sum = F::from(0);
+      typename F::Horner sum;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 8
 #endif
-      for (uint32_t j = 16; j-- > 0;) sum = F::add(F::mul_small(sum, 4), W(nl + 16 * i + j));
-      out.emit(F::sub(sum, W(i)));
+      for (uint32_t j = 16; j-- > 0;) sum.push(W(nl + 16 * i + j), 2);
+      out.emit(F::sub(sum.value(), W(i)));
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 8
 #endif
@@ -310,9 +334,19 @@ P2_HD void eval_gate(const GateDesc &g, WF W, CF LC, const typename F::T *pih, c
     const uint32_t nb = g.p[0], nc = g.p[1], cb = (nb + nc - 1) / nc;
     const uint32_t fc = 4, sc = 4 + nc, dm = 4 + 2 * nc, eq = 4 + 3 * nc, im = 4 + 4 * nc, msb = 4 + 5 * nc;
     T a = F::from(0), b = F::from(0);
-    for (uint32_t i = nc; i-- > 0;) {
-      a = F::add(F::mul_small(a, 1u << cb), W(fc + i));
-      b = F::add(F::mul_small(b, 1u << cb), W(sc + i));
+    if (cb * nc <= 63) {
+      typename F::Horner ha, hb;
+      for (uint32_t i = nc; i-- > 0;) {
+        ha.push(W(fc + i), cb);
+        hb.push(W(sc + i), cb);
+      }
+      a = ha.value();
+      b = hb.value();
+    } else {
+      for (uint32_t i = nc; i-- > 0;) {
+        a = F::add(F::mul_small(a, 1u << cb), W(fc + i));
+        b = F::add(F::mul_small(b, 1u << cb), W(sc + i));
+      }
     }
     out.emit(F::sub(a, W(0)));
     out.emit(F::sub(b, W(1)));

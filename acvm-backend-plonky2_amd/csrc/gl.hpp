@@ -88,6 +88,19 @@ P2_HD gl_t gl_mul(gl_t a, gl_t b) {
   return gl_reduce128(lo, hi);
 }
 P2_HD gl_t gl_sqr(gl_t a) { return gl_mul(a, a); }
+// a * b + c with one reduction: (p-1)^2 + p < 2^128, so the sum is formed unreduced
+P2_HD gl_t gl_mul_add(gl_t a, gl_t b, gl_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint64_t lo, hi;
+  gl_mul128(a, b, lo, hi);
+  lo += c;
+  hi += lo < c;
+#else
+  unsigned __int128 x = (unsigned __int128)a * b + c;
+  uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+#endif
+  return gl_reduce128(lo, hi);
+}
 // multiply by a small constant (< 2^32): the product fits in 96 bits
 P2_HD gl_t gl_mul_small(gl_t a, uint32_t k) {
 #if defined(__HIP_DEVICE_COMPILE__)

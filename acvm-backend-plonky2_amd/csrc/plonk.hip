@@ -54,8 +54,9 @@ __global__ __launch_bounds__(256) void zs_chunk_kernel(ZsArgs a) {
     gl_t pn = 1, pd = 1;
     for (uint32_t j = m * a.QF; j < (m + 1) * a.QF && j < a.R; j++) {
       gl_t wv = a.wires[(size_t)j * n + i];
-      gl_t num = gl_add(gl_add(wv, gl_mul(bx, a.k_is[j])), gamma);
-      gl_t den = gl_add(gl_add(wv, gl_mul(beta, a.sigmas[(size_t)j * n + i])), gamma);
+      const gl_t wg = gl_add(wv, gamma);
+      gl_t num = gl_mul_add(bx, a.k_is[j], wg);
+      gl_t den = gl_mul_add(beta, a.sigmas[(size_t)j * n + i], wg);
       pn = gl_mul(pn, num);
       pd = gl_mul(pd, den);
     }
@@ -242,11 +243,13 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
         const gl_t wv = wl[(size_t)j * n];
         const gl_t sg = cs[(size_t)(a.NC + j) * n];
         const gl_t kj = a.k_is[j];
-        n0 = gl_mul(n0, gl_add(gl_add(wv, gl_mul(bx0, kj)), a.gammas[0]));
-        d0 = gl_mul(d0, gl_add(gl_add(wv, gl_mul(a.betas[0], sg)), a.gammas[0]));
+        const gl_t wg0 = gl_add(wv, a.gammas[0]);
+        n0 = gl_mul(n0, gl_mul_add(bx0, kj, wg0));
+        d0 = gl_mul(d0, gl_mul_add(a.betas[0], sg, wg0));
         if (a.K > 1) {
-          n1 = gl_mul(n1, gl_add(gl_add(wv, gl_mul(bx1, kj)), a.gammas[1]));
-          d1 = gl_mul(d1, gl_add(gl_add(wv, gl_mul(a.betas[1], sg)), a.gammas[1]));
+          const gl_t wg1 = gl_add(wv, a.gammas[1]);
+          n1 = gl_mul(n1, gl_mul_add(bx1, kj, wg1));
+          d1 = gl_mul(d1, gl_mul_add(a.betas[1], sg, wg1));
         }
       }
       for (uint32_t c = 0; c < a.K; c++) {

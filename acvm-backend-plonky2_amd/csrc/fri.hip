@@ -45,14 +45,16 @@ __global__ __launch_bounds__(256) void eval_columns_kernel(const gl_t *__restric
   const uint32_t per = n / parts;
   const gl_t *c = coeffs + (size_t)col * n + (size_t)part * per;
   const gl_t *p0 = pw + (size_t)part * per, *p1 = pw + n + (size_t)part * per;
-  gl_t a0 = 0, a1 = 0;
+  Acc160 l0, l1;  // unreduced dot products (gl.hpp)
+  l0.clear();
+  l1.clear();
   for (uint32_t i = threadIdx.x; i < per; i += blockDim.x) {
     gl_t v = c[i];
-    a0 = gl_add(a0, gl_mul(v, p0[i]));
-    a1 = gl_add(a1, gl_mul(v, p1[i]));
+    l0.mac(v, p0[i]);
+    l1.mac(v, p1[i]);
   }
-  s0[threadIdx.x] = a0;
-  s1[threadIdx.x] = a1;
+  s0[threadIdx.x] = l0.value();
+  s1[threadIdx.x] = l1.value();
   __syncthreads();
   for (uint32_t off = blockDim.x >> 1; off; off >>= 1) {
     if (threadIdx.x < off) {
@@ -86,6 +88,9 @@ __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restr
   const bool live = p < n;
   gl_t a0 = 0, a1 = 0;
   if (live) {
+    Acc160 l0, l1;  // unreduced sums of products (gl.hpp)
+    l0.clear();
+    l1.clear();
     uint32_t j = g;
 #pragma unroll 1
     for (; j + 28 < cols; j += 32) {
@@ -94,15 +99,17 @@ __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restr
       for (int u = 0; u < 8; u++) v[u] = coeffs[(size_t)(j + 4 * u) * n + p];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        a0 = gl_add(a0, gl_mul(v[u], apow[2 * (j0 + j + 4 * u)]));
-        a1 = gl_add(a1, gl_mul(v[u], apow[2 * (j0 + j + 4 * u) + 1]));
+        l0.mac(v[u], apow[2 * (j0 + j + 4 * u)]);
+        l1.mac(v[u], apow[2 * (j0 + j + 4 * u) + 1]);
       }
     }
     for (; j < cols; j += 4) {
       const gl_t v = coeffs[(size_t)j * n + p];
-      a0 = gl_add(a0, gl_mul(v, apow[2 * (j0 + j)]));
-      a1 = gl_add(a1, gl_mul(v, apow[2 * (j0 + j) + 1]));
+      l0.mac(v, apow[2 * (j0 + j)]);
+      l1.mac(v, apow[2 * (j0 + j) + 1]);
     }
+    a0 = l0.value();
+    a1 = l1.value();
   }
   red[0][g][threadIdx.x] = a0;
   red[1][g][threadIdx.x] = a1;

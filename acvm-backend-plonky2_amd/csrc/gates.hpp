@@ -49,6 +49,19 @@ struct BaseOps {
     }
     P2_HD T value() const { return gl_reduce128(lo, hi); }
   };
+  // sum_i v_i k_i with small k_i (k_i < 2^20, < 2^10 terms): the two 32-bit halves of v are
+  // multiplied and summed separately in 64 bits (one v_mad_u64_u32 each), one reduction at the end
+  struct SmallDot {
+    uint64_t lo = 0, hi = 0;
+    P2_HD void add(T v, uint32_t k) {
+      lo += (uint64_t)(uint32_t)v * k;
+      hi += (v >> 32) * k;
+    }
+    P2_HD T value() const {
+      const uint64_t l = lo + (hi << 32);
+      return gl_reduce128(l, (hi >> 32) + (l < lo));
+    }
+  };
 };
 struct ExtOps {
   typedef ext_t T;
@@ -61,6 +74,11 @@ struct ExtOps {
   struct Horner {
     T acc = ext_make(0, 0);
     P2_HD void push(T v, uint32_t bits) { acc = add(mul_small(acc, 1u << bits), v); }
+    P2_HD T value() const { return acc; }
+  };
+  struct SmallDot {
+    T acc = ext_make(0, 0);
+    P2_HD void add(T v, uint32_t k) { acc = ExtOps::add(acc, mul_small(v, k)); }
     P2_HD T value() const { return acc; }
   };
 };
@@ -229,12 +247,13 @@ P2_HD void eval_gate(const GateDesc &g, WF W, CF LC, const typename F::T *pih, c
 #pragma unroll
 #endif
         for (int row = 0; row < 12; row++) {
-          T acc = F::mul_small(st[row], POSEIDON_MDS_CIRC[0] + (row == 0 ? POSEIDON_MDS_DIAG0 : 0));
+          typename F::SmallDot acc;
+          acc.add(st[row], POSEIDON_MDS_CIRC[0] + (row == 0 ? POSEIDON_MDS_DIAG0 : 0));
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-          for (int i = 1; i < 12; i++) acc = F::add(acc, F::mul_small(st[(i + row) % 12], POSEIDON_MDS_CIRC[i]));
-          nx[row] = acc;
+          for (int i = 1; i < 12; i++) acc.add(st[(i + row) % 12], POSEIDON_MDS_CIRC[i]);
+          nx[row] = acc.value();
         }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll

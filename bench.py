@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--degree-bits", type=int, default=17)
     ap.add_argument("--mix", default="sha")
+    ap.add_argument("--public-inputs", type=int, default=0,
+                    help="public inputs of the synthetic circuit (> 0 adds PoseidonGate rows to the circuit and the "
+                         "PoseidonGate to the gate set every LDE row evaluates); 0 = the BASELINE parity shape")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="independent proofs in flight per GPU (separate circuit handles / HIP streams, one host "
                          "thread each): hides the latency-bound Merkle-tree tails and host round trips of one proof "
@@ -117,7 +120,9 @@ def main():
     d, mix = args.degree_bits, args.mix
     # every rank proves its own witness of the same circuit shape (independent proofs)
     sharded = args.mode == "sharded" and world > 1
-    blob, wires = pkg.make_circuit(d, mix, seed=1 if sharded else 1 + rank)
+    made = pkg.make_circuit(d, mix, seed=1 if sharded else 1 + rank, num_public_inputs=args.public_inputs)
+    blob, wires = made[0], made[1]
+    pis = made[2] if args.public_inputs else ()
     S = 1 if sharded else max(1, min(args.in_flight, args.steps))
     cds = [pkg.CircuitData(blob) for _ in range(S)]
     if sharded:
@@ -137,7 +142,7 @@ def main():
         def work(i):
             last = None
             for _ in range(i, n_proofs, S):
-                last = cds[i].prove(wires_dev)
+                last = cds[i].prove(wires_dev, public_inputs=pis)
                 if collect is not None:
                     collect.append(last.timings)
             results[i] = last
@@ -172,11 +177,11 @@ def main():
             if k.endswith("_ms"):
                 phase[k] = phase.get(k, 0.0) + v
     # single-proof latency (nothing else in flight), measured after the timed region
-    cds[0].prove(wires_dev)
+    cds[0].prove(wires_dev, public_inputs=pis)
     torch.cuda.synchronize()
     tl = time.perf_counter()
     for _ in range(3):
-        cds[0].prove(wires_dev)
+        cds[0].prove(wires_dev, public_inputs=pis)
     latency_ms = (time.perf_counter() - tl) / 3 * 1e3
     cd = cds[0]
 
@@ -202,7 +207,7 @@ def main():
             "config": {
                 "workload": f"synth(d={d},{mix}): {1 << d} gates -> 2^{d + 3} LDE rows, 234 wires / 80 routed, "
                             f"KeccakGoldilocksConfig, rate 8, cap 2^4, 28 queries, 16 PoW bits (BASELINE configs[2] shape)",
-                "degree_bits": d, "lde_rows": 1 << (d + 3), "mix": mix,
+                "degree_bits": d, "lde_rows": 1 << (d + 3), "mix": mix, "public_inputs": args.public_inputs,
                 "parallelism": (f"one proof coset-sharded over {world} GPUs (8/{world} LDE cosets each; all-gather of caps, "
                                 f"quotient interpolants, query openings)" if sharded else
                                 f"replicas x{world} (independent proofs per GPU, no data-path collective), "

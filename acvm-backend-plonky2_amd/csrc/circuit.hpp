@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include <exception>
+
 namespace p2 {
 
 // thread-local message behind p2gpu_last_error()
@@ -157,6 +159,18 @@ struct CircuitState {
 };
 
 }  // namespace p2
+
+// closes the function-try-block of a C ABI entry point: no C++ exception (std::bad_alloc from a host
+// container, ...) may cross the boundary
+#define P2GPU_CATCH                                                   \
+  catch (const std::exception &e) {                                   \
+    p2::set_err("internal error: %s", e.what());                      \
+    return P2GPU_E_DEVICE;                                            \
+  }                                                                   \
+  catch (...) {                                                       \
+    p2::set_err("internal error");                                    \
+    return P2GPU_E_DEVICE;                                            \
+  }
 
 struct p2gpu_circuit : p2::CircuitState {};
 

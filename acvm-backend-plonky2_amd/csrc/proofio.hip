@@ -482,31 +482,31 @@ int emit(const Out &o, uint8_t *out, size_t *out_len) {
 
 extern "C" {
 
-int p2gpu_proof_compress(const p2gpu_circuit *c, const uint8_t *proof, size_t len, uint8_t *out, size_t *out_len) {
+int p2gpu_proof_compress(const p2gpu_circuit *c, const uint8_t *proof, size_t len, uint8_t *out, size_t *out_len) try {
   if (!c || !proof || !out_len) return P2GPU_E_ARG;
   ProofData P;
   if (int rc = parse_uncompressed(c, proof, len, P)) return rc;
   Out o;
   if (int rc = do_compress(c, P, o)) return rc;
   return emit(o, out, out_len);
-}
+} P2GPU_CATCH
 
-int p2gpu_proof_decompress(const p2gpu_circuit *c, const uint8_t *cproof, size_t len, uint8_t *out, size_t *out_len) {
+int p2gpu_proof_decompress(const p2gpu_circuit *c, const uint8_t *cproof, size_t len, uint8_t *out, size_t *out_len) try {
   if (!c || !cproof || !out_len) return P2GPU_E_ARG;
   ProofData P;
   if (int rc = do_decompress(c, cproof, len, P)) return rc;
   Out o;
   write_uncompressed(P, o);
   return emit(o, out, out_len);
-}
+} P2GPU_CATCH
 
-int p2gpu_verify_compressed(const p2gpu_circuit *c, const uint8_t *cproof, size_t len) {
+int p2gpu_verify_compressed(const p2gpu_circuit *c, const uint8_t *cproof, size_t len) try {
   if (!c || !cproof) return P2GPU_E_ARG;
   ProofData P;
   if (int rc = do_decompress(c, cproof, len, P)) return rc;
   Out o;
   write_uncompressed(P, o);
   return p2gpu_verify(c, o.v.data(), o.v.size());
-}
+} P2GPU_CATCH
 
 }  // extern "C"

@@ -894,7 +894,7 @@ size_t p2gpu_proof_size_bound(const p2gpu_circuit *c) {
   return sz;
 }
 
-int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c) {
+int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c) try {
   if (!blob || !out_c) return P2GPU_E_ARG;
   if (int rc = ensure_device()) return rc;
   p2gpu_circuit *c = new p2gpu_circuit();
@@ -1135,7 +1135,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
 #undef CK
   *out_c = c;
   return P2GPU_OK;
-}
+} P2GPU_CATCH
 
 void p2gpu_circuit_destroy(p2gpu_circuit *c) {
   if (!c) return;
@@ -1158,7 +1158,7 @@ int p2gpu_circuit_digest(const p2gpu_circuit *c, uint8_t out[25]) {
   return P2GPU_OK;
 }
 
-int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) {
+int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
   if (!c || !key) return P2GPU_E_ARG;
   if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
   std::string k(key);
@@ -1173,9 +1173,9 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) {
     return P2GPU_E_ARG;
   }
   return P2GPU_OK;
-}
+} P2GPU_CATCH
 
-int p2gpu_circuit_set_shard(p2gpu_circuit *c, int rank, int world, p2gpu_allgather_fn fn, void *ctx) {
+int p2gpu_circuit_set_shard(p2gpu_circuit *c, int rank, int world, p2gpu_allgather_fn fn, void *ctx) try {
   if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn) || (c->C % (uint32_t)world) != 0) {
     set_err("bad shard configuration: rank %d of %d (cosets %u)", rank, world, c ? c->C : 0u);
     return P2GPU_E_ARG;
@@ -1208,11 +1208,11 @@ int p2gpu_circuit_set_shard(p2gpu_circuit *c, int rank, int world, p2gpu_allgath
   c->xchg_recv.release();
   if (world > 1) HIP_TRY(c->xchg_recv.alloc((size_t)world * c->gather_cap + 64));
   return P2GPU_OK;
-}
+} P2GPU_CATCH
 
 // per-kernel event timings accumulated while "profile" = 1: writes up to `cap`
 // entries "name\0" (64 B each) + total ms + launch count; returns the number of entries
-int p2gpu_kernel_stats(p2gpu_circuit *c, char *names, double *ms, double *bytes, uint64_t *launches, int cap) {
+int p2gpu_kernel_stats(p2gpu_circuit *c, char *names, double *ms, double *bytes, uint64_t *launches, int cap) try {
   if (!c) return P2GPU_E_ARG;
   if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
   (void)hipSetDevice(c->device);
@@ -1228,9 +1228,9 @@ int p2gpu_kernel_stats(p2gpu_circuit *c, char *names, double *ms, double *bytes,
     i++;
   }
   return i;
-}
+} P2GPU_CATCH
 
-int p2gpu_fill_witness(p2gpu_circuit *c, uint64_t *wires_dev) {
+int p2gpu_fill_witness(p2gpu_circuit *c, uint64_t *wires_dev) try {
   if (!c || !wires_dev) return P2GPU_E_ARG;
   if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
   HIP_TRY(hipSetDevice(c->device));
@@ -1238,10 +1238,10 @@ int p2gpu_fill_witness(p2gpu_circuit *c, uint64_t *wires_dev) {
                c->W);
   HIP_TRY(hipStreamSynchronize(c->stream));
   return P2GPU_OK;
-}
+} P2GPU_CATCH
 
 int p2gpu_prove_routed(p2gpu_circuit *c, const uint64_t *routed, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
-                       size_t *proof_len, p2gpu_timings *tm) {
+                       size_t *proof_len, p2gpu_timings *tm) try {
   if (!c || !routed || !proof_out || !proof_len) return P2GPU_E_ARG;
   if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
   HIP_TRY(hipSetDevice(c->device));
@@ -1254,17 +1254,17 @@ int p2gpu_prove_routed(p2gpu_circuit *c, const uint64_t *routed, const uint64_t 
   HIP_TRY(hipStreamSynchronize(c->stream));
   double h2d = now_ms() - t0;
   return prove_impl(c, c->wires_vals.p, pis, n_pi, proof_out, proof_len, tm, h2d);
-}
+} P2GPU_CATCH
 
 int p2gpu_prove_dev(p2gpu_circuit *c, const uint64_t *wires_dev, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
-                    size_t *proof_len, p2gpu_timings *tm) {
+                    size_t *proof_len, p2gpu_timings *tm) try {
   if (!c || !wires_dev || !proof_out || !proof_len) return P2GPU_E_ARG;
   if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
   return prove_impl(c, wires_dev, pis, n_pi, proof_out, proof_len, tm, 0.0);
-}
+} P2GPU_CATCH
 
 int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
-                size_t *proof_len, p2gpu_timings *tm) {
+                size_t *proof_len, p2gpu_timings *tm) try {
   if (!c || !wires || !proof_out || !proof_len) return P2GPU_E_ARG;
   if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
   HIP_TRY(hipSetDevice(c->device));
@@ -1297,10 +1297,10 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
   int rc = prove_impl(c, c->wires_vals.p, pis, n_pi, proof_out, proof_len, tm, h2d);
   c->wires_ntt_done = false;
   return rc;
-}
+} P2GPU_CATCH
 
 // ---- stage-level operators (host buffers) ----
-int p2gpu_ifft_batch(const uint64_t *vals, size_t ncols, unsigned d, uint64_t *coeffs_out) {
+int p2gpu_ifft_batch(const uint64_t *vals, size_t ncols, unsigned d, uint64_t *coeffs_out) try {
   if (int rc = ensure_device()) return rc;
   if (!vals || !coeffs_out || d > 24) return P2GPU_E_ARG;
   Scratch S;
@@ -1319,9 +1319,9 @@ int p2gpu_ifft_batch(const uint64_t *vals, size_t ncols, unsigned d, uint64_t *c
   HIP_TRY(e1);
   HIP_TRY(e2);
   return P2GPU_OK;
-}
+} P2GPU_CATCH
 
-int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned rate_bits, uint64_t *lde_out) {
+int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned rate_bits, uint64_t *lde_out) try {
   if (int rc = ensure_device()) return rc;
   if (!coeffs || !lde_out || d > 24 || rate_bits > 3) return P2GPU_E_ARG;
   Scratch S;
@@ -1348,9 +1348,9 @@ int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned r
     for (size_t col = 0; col < ncols; col++)
       for (size_t k = 0; k < n; k++) lde_out[col * C * n + C * k + r] = tmp[((size_t)r * ncols + col) * n + k];
   return P2GPU_OK;
-}
+} P2GPU_CATCH
 
-int p2gpu_hash_rows(const uint64_t *rows, size_t n_rows, size_t row_len, uint8_t *digests_out) {
+int p2gpu_hash_rows(const uint64_t *rows, size_t n_rows, size_t row_len, uint8_t *digests_out) try {
   if (int rc = ensure_device()) return rc;
   if (!rows || !digests_out) return P2GPU_E_ARG;
   Scratch S;
@@ -1365,10 +1365,10 @@ int p2gpu_hash_rows(const uint64_t *rows, size_t n_rows, size_t row_len, uint8_t
   HIP_TRY(hipStreamSynchronize(S.st));
   for (size_t i = 0; i < n_rows; i++) memcpy(digests_out + 25 * i, h[i].w, 25);
   return P2GPU_OK;
-}
+} P2GPU_CATCH
 
 int p2gpu_commit_values(const uint64_t *vals, size_t ncols, unsigned d, unsigned rate_bits, unsigned cap_h,
-                        uint8_t *cap_out) {
+                        uint8_t *cap_out) try {
   if (int rc = ensure_device()) return rc;
   if (!vals || !cap_out || d > 24 || rate_bits > 3 || cap_h < rate_bits || cap_h > rate_bits + d) return P2GPU_E_ARG;
   // a throw-away circuit-like context with just the tables and one batch
@@ -1405,6 +1405,6 @@ int p2gpu_commit_values(const uint64_t *vals, size_t ncols, unsigned d, unsigned
   circuit_release(c);
   delete c;
   return rc;
-}
+} P2GPU_CATCH
 
 }  // extern "C"

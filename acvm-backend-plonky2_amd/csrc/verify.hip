@@ -103,7 +103,7 @@ int reject(const char *fmt, ...) {
 
 extern "C" {
 
-int p2gpu_verifier_create(const uint8_t *blob, size_t len, p2gpu_circuit **out) {
+int p2gpu_verifier_create(const uint8_t *blob, size_t len, p2gpu_circuit **out) try {
   if (!blob || !out) return P2GPU_E_ARG;
   p2gpu_circuit *c = new p2gpu_circuit();
   size_t off = 0;
@@ -125,10 +125,10 @@ int p2gpu_verifier_create(const uint8_t *blob, size_t len, p2gpu_circuit **out) 
   c->device = -1;  // no device state: only p2gpu_verify and the getters accept this handle
   *out = c;
   return P2GPU_OK;
-}
+} P2GPU_CATCH
 
 // header | gate table | cap | k_is: the verifier's share of a circuit blob
-int p2gpu_circuit_export_vk(const p2gpu_circuit *c, uint8_t *out, size_t *len) {
+int p2gpu_circuit_export_vk(const p2gpu_circuit *c, uint8_t *out, size_t *len) try {
   if (!c || !len) return P2GPU_E_ARG;
   const size_t ncap = (size_t)1 << c->cap_h;
   const size_t need = 256 + 48 * (size_t)c->num_gates + 32 * ncap + 8 * (size_t)c->R;
@@ -167,9 +167,9 @@ int p2gpu_circuit_export_vk(const p2gpu_circuit *c, uint8_t *out, size_t *len) {
   off += 8 * (size_t)c->R;
   *len = off;
   return P2GPU_OK;
-}
+} P2GPU_CATCH
 
-int p2gpu_verify(const p2gpu_circuit *c, const uint8_t *proof, size_t len) {
+int p2gpu_verify(const p2gpu_circuit *c, const uint8_t *proof, size_t len) try {
   if (!c || !proof) return P2GPU_E_ARG;
   const uint32_t K = c->K, R = c->R, W = c->W, NC = c->NC, QF = c->QF, PP = c->PP, d = c->d;
   const uint32_t ncs = NC + R, nzp = K * (1 + PP), nq = K * QF, nall = ncs + W + nzp + nq;
@@ -326,6 +326,6 @@ int p2gpu_verify(const p2gpu_circuit *c, const uint8_t *proof, size_t len) {
   }
   if (!in.ok || in.at != tail_at) return reject("query section has the wrong size");
   return P2GPU_OK;
-}
+} P2GPU_CATCH
 
 }  // extern "C"

@@ -109,6 +109,80 @@ P2_HD typename F::T ra_fold(WF &W, uint32_t item0, const typename F::T *bv) {
   }
 }
 
+// PoseidonGate (plonky2 gates/poseidon.rs), on its own so that a kernel can evaluate just this gate.
+template <class F, class WF, class OUT>
+P2_HD void eval_poseidon_gate(WF W, const gl_t *prc, OUT &out) {
+  typedef typename F::T T;
+  // plonky2 gates/poseidon.rs.  Partial rounds in plain form: the S-box inputs (the only
+  // non-linear points) equal those of upstream's fast factorisation, so all 123 constraint
+  // values coincide.  Wires: in 0..11, out 12..23, swap 24, delta 25..28, full-0 S-box
+  // inputs 29.. (rounds 1-3), partial 65.., full-1 87..
+  T st[12];
+  const T swap = W(24);
+  out.emit(F::mul(swap, F::sub(swap, F::from(1))));
+  for (int i = 0; i < 4; i++) {
+    const T l = W(i), r = W(i + 4), dl = W(25 + i);
+    out.emit(F::sub(F::mul(swap, F::sub(r, l)), dl));
+    st[i] = F::add(l, dl);
+    st[i + 4] = F::sub(r, dl);
+  }
+  for (int i = 8; i < 12; i++) st[i] = W(i);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int r = 0; r < 30; r++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 12; i++) st[i] = F::add(st[i], F::from(prc[12 * r + i]));
+    const bool full = r < 4 || r >= 26;
+    if (full) {
+      if (r != 0) {
+        const uint32_t base = r < 4 ? 29 + 12 * (r - 1) : 87 + 12 * (r - 26);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 12; i++) {
+          const T sb = W(base + i);
+          out.emit(F::sub(st[i], sb));
+          st[i] = sb;
+        }
+      }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int i = 0; i < 12; i++) {
+        T x2 = F::mul(st[i], st[i]), x4 = F::mul(x2, x2), x3 = F::mul(x2, st[i]);
+        st[i] = F::mul(x4, x3);
+      }
+    } else {
+      const T sb = W(65 + (r - 4));
+      out.emit(F::sub(st[0], sb));
+      T x2 = F::mul(sb, sb), x4 = F::mul(x2, x2), x3 = F::mul(x2, sb);
+      st[0] = F::mul(x4, x3);
+    }
+    // MDS layer: out[row] = sum_i st[(i + row) % 12] * CIRC[i] + st[row] * DIAG[row]
+    T nx[12];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int row = 0; row < 12; row++) {
+      typename F::SmallDot acc;
+      acc.add(st[row], POSEIDON_MDS_CIRC[0] + (row == 0 ? POSEIDON_MDS_DIAG0 : 0));
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int i = 1; i < 12; i++) acc.add(st[(i + row) % 12], POSEIDON_MDS_CIRC[i]);
+      nx[row] = acc.value();
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 12; i++) st[i] = nx[i];
+  }
+  for (int i = 0; i < 12; i++) out.emit(F::sub(st[i], W(12 + i)));
+    }
+
 // W(c): wire column c of this row; LC(i): local constant i; pih: public_inputs_hash;
 // prc: the 360 Poseidon round constants (only read when POSEIDON); out.emit(c) consumes
 // the constraints in order.
@@ -192,76 +266,7 @@ P2_HD void eval_gate(const GateDesc &g, WF W, CF LC, const typename F::T *pih, c
     break;
   }
   case G_POSEIDON:
-    if constexpr (POSEIDON) {
-      // plonky2 gates/poseidon.rs.  Partial rounds in plain form: the S-box inputs (the only
-      // non-linear points) equal those of upstream's fast factorisation, so all 123 constraint
-      // values coincide.  Wires: in 0..11, out 12..23, swap 24, delta 25..28, full-0 S-box
-      // inputs 29.. (rounds 1-3), partial 65.., full-1 87..
-      T st[12];
-      const T swap = W(24);
-      out.emit(F::mul(swap, F::sub(swap, F::from(1))));
-      for (int i = 0; i < 4; i++) {
-        const T l = W(i), r = W(i + 4), dl = W(25 + i);
-        out.emit(F::sub(F::mul(swap, F::sub(r, l)), dl));
-        st[i] = F::add(l, dl);
-        st[i + 4] = F::sub(r, dl);
-      }
-      for (int i = 8; i < 12; i++) st[i] = W(i);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
-      for (int r = 0; r < 30; r++) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int i = 0; i < 12; i++) st[i] = F::add(st[i], F::from(prc[12 * r + i]));
-        const bool full = r < 4 || r >= 26;
-        if (full) {
-          if (r != 0) {
-            const uint32_t base = r < 4 ? 29 + 12 * (r - 1) : 87 + 12 * (r - 26);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int i = 0; i < 12; i++) {
-              const T sb = W(base + i);
-              out.emit(F::sub(st[i], sb));
-              st[i] = sb;
-            }
-          }
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-          for (int i = 0; i < 12; i++) {
-            T x2 = F::mul(st[i], st[i]), x4 = F::mul(x2, x2), x3 = F::mul(x2, st[i]);
-            st[i] = F::mul(x4, x3);
-          }
-        } else {
-          const T sb = W(65 + (r - 4));
-          out.emit(F::sub(st[0], sb));
-          T x2 = F::mul(sb, sb), x4 = F::mul(x2, x2), x3 = F::mul(x2, sb);
-          st[0] = F::mul(x4, x3);
-        }
-        // MDS layer: out[row] = sum_i st[(i + row) % 12] * CIRC[i] + st[row] * DIAG[row]
-        T nx[12];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int row = 0; row < 12; row++) {
-          typename F::SmallDot acc;
-          acc.add(st[row], POSEIDON_MDS_CIRC[0] + (row == 0 ? POSEIDON_MDS_DIAG0 : 0));
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-          for (int i = 1; i < 12; i++) acc.add(st[(i + row) % 12], POSEIDON_MDS_CIRC[i]);
-          nx[row] = acc.value();
-        }
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int i = 0; i < 12; i++) st[i] = nx[i];
-      }
-      for (int i = 0; i < 12; i++) out.emit(F::sub(st[i], W(12 + i)));
-    }
+    if constexpr (POSEIDON) eval_poseidon_gate<F>(W, prc, out);
     break;
   case G_U32_ARITHMETIC: {
     const uint32_t ops = g.p[0];

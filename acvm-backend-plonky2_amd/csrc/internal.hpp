@@ -88,6 +88,7 @@ struct QuotArgs {
   const gl_t *tw;        // w_n^i forward table
   const gl_t *apow;      // [K][nterms] alpha powers
   const GateDesc *gates; // device copy
+  const GateDesc *host_gates;  // the same table on the host (launch-time decisions)
   gl_t *out;             // [K][cosets][n]
   uint32_t tw_shift, d, rate_bits, W, R, NC, num_selectors, K, QF, nchunks, PP, num_gates, nterms, has_poseidon;
   uint32_t gate_groups;  // 1, or 4: gates split over the four waves of a 64-row block (GateDesc.pad = group)

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
   for (uint32_t gi = 0; gi < a.num_gates; gi++) {
     const GateDesc g = a.gates[gi];
     if (g.num_constraints == 0) continue;
+    if (!POSEIDON && g.kind == G_POSEIDON) continue;  // evaluated by poseidon_gate_kernel
     if (G > 1 && g.pad != grp) continue;
     const gl_t s = cs[(size_t)g.sel_index * n];
     const gl_t f = gate_filter<BaseOps>(g, gi, a.num_selectors, s);
@@ -270,22 +271,57 @@ __global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
   if (a.K > 1) a.out[((size_t)1 * a.ncosets + z) * n + k] = gl_mul(tot1, zi);
 }
 
+// The PoseidonGate term on its own grid (circuits with public inputs): 118 S-boxes and 30 MDS layers
+// per LDE row are as much work as the rest of the row together, and inside the generic kernel they
+// set its register budget (155 VGPRs -> 3 waves per SIMD).  Adds filter(x) * sum_t alpha^t c_t / Z_H(x)
+// to what quotient_kernel wrote.
+__global__ __launch_bounds__(256) void poseidon_gate_kernel(const QuotArgs a, uint32_t gi) {
+  const uint32_t n = 1u << a.d;
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t z = blockIdx.y;
+  const uint32_t r = a.coset_first + z * a.coset_stride;
+  if (k >= n) return;
+  const GateDesc g = a.gates[gi];
+  const uint32_t ncs = a.NC + a.R;
+  const gl_t *cs = a.cs_lde + (size_t)r * ncs * n + k;
+  const gl_t *wl = a.wires_lde + (size_t)z * a.W * n + k;
+  Consumer out;
+  out.acc0.clear();
+  out.acc1.clear();
+  out.ap0 = a.apow;
+  out.ap1 = a.apow + a.nterms;
+  out.t = a.K + a.K * a.nchunks;
+  auto W = [&](uint32_t c) { return wl[(size_t)c * n]; };
+  eval_poseidon_gate<BaseOps>(W, c_poseidon_rc, out);
+  const gl_t f = gate_filter<BaseOps>(g, gi, a.num_selectors, cs[(size_t)g.sel_index * n]);
+  const gl_t fz = gl_mul(f, a.qconst[16 + r]);
+  gl_t *o0 = a.out + ((size_t)0 * a.ncosets + z) * n + k;
+  *o0 = gl_mul_add(fz, out.acc0.value(), *o0);
+  if (a.K > 1) {
+    gl_t *o1 = a.out + ((size_t)1 * a.ncosets + z) * n + k;
+    *o1 = gl_mul_add(fz, out.acc1.value(), *o1);
+  }
+}
+
 void quotient_eval(hipStream_t st, const QuotArgs &a) {
   const uint32_t n = 1u << a.d;
   const uint32_t threads = n >= 256 ? 256 : 64;
   const bool split = a.gate_groups == 4 && n >= 64;
   // same spelling as rocprofv3's demangled names
-  const char *name = split ? (a.has_poseidon ? "quotient_kernel<true, 4>" : "quotient_kernel<false, 4>")
-                           : (a.has_poseidon ? "quotient_kernel<true, 1>" : "quotient_kernel<false, 1>");
-  ProfScope ps(name, 8.0 * (double)n * a.ncosets * (a.NC + a.R + a.W + a.K * (1 + a.PP) + 2.0 * a.K));
-  if (split) {
-    dim3 grid(n / 64, a.ncosets), block(64, 4);
-    if (a.has_poseidon) hipLaunchKernelGGL((quotient_kernel<true, 4>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((quotient_kernel<false, 4>), grid, block, 0, st, a);
-  } else {
-    dim3 grid((n + threads - 1) / threads, a.ncosets), block(threads);
-    if (a.has_poseidon) hipLaunchKernelGGL((quotient_kernel<true, 1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((quotient_kernel<false, 1>), grid, block, 0, st, a);
+  {
+    const char *name = split ? "quotient_kernel<false, 4>" : "quotient_kernel<false, 1>";
+    ProfScope ps(name, 8.0 * (double)n * a.ncosets * (a.NC + a.R + a.W + a.K * (1 + a.PP) + 2.0 * a.K));
+    if (split) {
+      hipLaunchKernelGGL((quotient_kernel<false, 4>), dim3(n / 64, a.ncosets), dim3(64, 4), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((quotient_kernel<false, 1>), dim3((n + threads - 1) / threads, a.ncosets), dim3(threads), 0, st, a);
+    }
+  }
+  if (a.has_poseidon) {
+    uint32_t gi = 0;
+    while (gi < a.num_gates && a.host_gates[gi].kind != G_POSEIDON) gi++;
+    ProfScope ps("poseidon_gate_kernel", 8.0 * (double)n * a.ncosets * (135 + 1 + 4.0 * a.K));
+    hipLaunchKernelGGL(poseidon_gate_kernel, dim3((n + threads - 1) / threads, a.ncosets), dim3(threads), 0, st, a, gi);
   }
 }
 

@@ -357,6 +357,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     q.tw = c->tw_fwd.p;
     q.apow = c->apow.p;
     q.gates = c->d_gates.p;
+    q.host_gates = c->gates.data();
     q.out = c->qvals.p;
     q.tw_shift = 0; q.d = d; q.rate_bits = c->rate_bits; q.W = W; q.R = R; q.NC = NC;
     q.num_selectors = c->num_selectors; q.K = K; q.QF = QF; q.nchunks = c->nchunks; q.PP = PP;
@@ -915,17 +916,13 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   {
     // heavy gate mixes: split the gates over 4 waves that share a row tile (plonk.hip); greedy
     // balance by an estimate of modmuls per row, group 0 starts with the permutation argument
-    auto cost = [](const GateDesc &g) { return g.kind == G_POSEIDON ? 1600u : 4u * g.num_constraints + 8u; };
+    // (a PoseidonGate is not part of this: it has its own kernel, plonk.hip poseidon_gate_kernel)
+    auto cost = [](const GateDesc &g) { return g.kind == G_POSEIDON ? 0u : 4u * g.num_constraints + 8u; };
     const uint32_t perm_cost = 8u * c->R + 100u;
     uint32_t total = 0;
     for (auto &g : c->gates) total += cost(g);
-    // A PoseidonGate (any circuit with public inputs) is most of the work on its own and cannot be
-    // balanced over four waves: measured at 2^20 rows, 1 group 2.5 ms vs 4 groups 3.9 ms (sha mix),
-    // 6.5 vs 7.1 ms (all gate kinds) -- so such circuits keep one lane per row.
-    bool has_poseidon = false;
-    for (auto &g : c->gates) has_poseidon |= g.kind == G_POSEIDON;
     const char *env = getenv("P2GPU_GATE_GROUPS");
-    c->gate_groups = env ? (uint32_t)atoi(env) : (!has_poseidon && total > 2 * perm_cost ? 4u : 1u);
+    c->gate_groups = env ? (uint32_t)atoi(env) : (total > 2 * perm_cost ? 4u : 1u);
     if (c->gate_groups != 4) c->gate_groups = 1;
     uint32_t load[4] = {perm_cost, 0, 0, 0};
     std::vector<uint32_t> order(c->gates.size());

@@ -125,6 +125,8 @@ struct CircuitState {
   hipStream_t copy_stream = nullptr;  // H2D of the witness, overlapped with the transforms of earlier columns
   std::vector<hipEvent_t> copy_events;
   bool wires_ntt_done = false;        // set by p2gpu_prove: coefficients + LDE of the wires already enqueued
+  bool wires_hash_done = false;       // ... and the leaf digests too (incremental sponge, hash_state)
+  DBuf<uint64_t> hash_state;          // [cosets][25][n] sponge states between column chunks (allocated on first use)
   // tables
   DBuf<gl_t> tw_fwd, tw_inv, scale, inv_scale, d_kis, d_sigmas, fri_scale, qconst;
   DBuf<GateDesc> d_gates;

@@ -61,6 +61,10 @@ void hash_rows(hipStream_t st, const gl_t *rows, size_t n_rows, uint32_t row_len
 void hash_fri_leaves(hipStream_t st, const gl_t *vals, uint32_t lg_npc, uint32_t cosets, uint32_t arity_bits,
                      dig_t *dig);
 // one tree level: in [cosets][m] -> out [cosets][m/2], out[c][k] = H(in[c][k], in[c][k + m/2])
+// incremental variant: absorb the rate blocks [blk0, blk0 + nblk) (17 columns each) into the sponge
+// states kept in `state` ([cosets][25][n]); `last` also absorbs the tail + padding and writes digests
+void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, uint32_t blk0,
+                     uint32_t nblk, bool first, bool last, uint64_t *state, dig_t *dig);
 void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m);
 // every level below one with m <= 4096 nodes per coset, down to cap_per nodes per coset, in one launch
 void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per);

@@ -76,6 +76,46 @@ __global__ __launch_bounds__(256) void hash_lde_leaves_kernel(const gl_t *__rest
   dig[(size_t)c * n + k] = hash_or_noop(cols, [&](uint32_t i) { return base[(size_t)i * n]; });
 }
 
+// Leaf hashing for a witness that arrives in column chunks (p2gpu_prove): a Keccak sponge absorbs
+// 17 columns per permutation, in column order, so the rate blocks of the columns already on the
+// device can be absorbed while later columns are still crossing PCIe.  The 25-word state of every
+// row waits in HBM between calls ([coset][25][n], word-major: coalesced); the call with `last` also
+// absorbs the ragged tail with the padding and writes the digest.
+__global__ __launch_bounds__(256) void hash_lde_absorb_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
+                                                              uint32_t blk0, uint32_t nblk, int first, int last,
+                                                              uint64_t *__restrict__ state, dig_t *__restrict__ dig) {
+  const size_t n = (size_t)1 << d;
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = blockIdx.y;
+  if (k >= n) return;
+  const gl_t *base = lde + (size_t)c * cols * n + k;
+  uint64_t *sp = state + (size_t)c * 25 * n + k;
+  uint64_t st[25];
+#pragma unroll
+  for (int i = 0; i < 25; i++) st[i] = first ? 0 : sp[(size_t)i * n];
+  for (uint32_t b = 0; b < nblk; b++) {
+    const gl_t *col = base + (size_t)17 * (blk0 + b) * n;
+#pragma unroll
+    for (int w = 0; w < 17; w++) st[w] ^= col[(size_t)w * n];
+    keccak_f1600(st);
+  }
+  if (last) {
+    const uint32_t off = 17 * (blk0 + nblk), rem = cols - off;  // rem < 17
+    const gl_t *col = base + (size_t)off * n;
+#pragma unroll
+    for (int w = 0; w < 17; w++) {
+      if ((uint32_t)w < rem) st[w] ^= col[(size_t)w * n];
+      if ((uint32_t)w == rem) st[w] ^= 0x01ULL;
+    }
+    st[16] ^= 0x8000000000000000ULL;
+    keccak_f1600(st);
+    dig[(size_t)c * n + k] = dig_from_state(st);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 25; i++) sp[(size_t)i * n] = st[i];
+  }
+}
+
 __global__ __launch_bounds__(256) void hash_rows_kernel(const gl_t *__restrict__ rows, size_t n_rows, uint32_t row_len,
                                                         dig_t *__restrict__ dig) {
   const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -141,6 +181,15 @@ void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d,
   ProfScope ps("hash_lde_leaves_kernel", (8.0 * cols + 32.0) * cosets * (double)n);
   hipLaunchKernelGGL(hash_lde_leaves_kernel, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols,
                      d, dig);
+}
+void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, uint32_t blk0,
+                     uint32_t nblk, bool first, bool last, uint64_t *state, dig_t *dig) {
+  size_t n = (size_t)1 << d;
+  uint32_t threads = n >= 256 ? 256 : 64;
+  ProfScope ps("hash_lde_absorb_kernel", (8.0 * 17 * nblk + (first ? 0 : 200) + (last ? 32 + 8.0 * (cols - 17 * (blk0 + nblk)) : 200)) *
+                                             cosets * (double)n);
+  hipLaunchKernelGGL(hash_lde_absorb_kernel, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols,
+                     d, blk0, nblk, first ? 1 : 0, last ? 1 : 0, state, dig);
 }
 void hash_rows(hipStream_t st, const gl_t *rows, size_t n_rows, uint32_t row_len, dig_t *dig) {
   hipLaunchKernelGGL(hash_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, st, rows, n_rows, row_len, dig);

@@ -219,7 +219,7 @@ int batch_commit_from_lde(p2gpu_circuit *c, Batch &b) {
   return tree_build(c, b, c->n);
 }
 int batch_commit_from_values(p2gpu_circuit *c, Batch &b, const gl_t *vals_dev) {
-  if (&b == &c->wires && c->wires_ntt_done) return batch_commit_from_lde(c, b);
+  if (&b == &c->wires && c->wires_ntt_done) return c->wires_hash_done ? tree_build(c, b, c->n) : batch_commit_from_lde(c, b);
   {
     gl_t ninv = gl_inv((gl_t)c->n);
     ntt_batch(c->stream, c->plan_inv, vals_dev, b.coeffs.p, b.cols, 1, nullptr, ninv, false);
@@ -709,6 +709,7 @@ void circuit_release(p2gpu_circuit *c) {
   for (auto &b : c->fri_coef) b.release();
   for (auto &b : c->fri_vals) b.release();
   for (auto &b : c->fri_trees) b.release();
+  c->hash_state.release();
   c->pow_result.release(); c->gather_ptrs.release(); c->gather_out.release(); c->xchg_recv.release();
   ntt_plan_destroy(c->plan_inv);
   ntt_plan_destroy(c->plan_fwd);
@@ -1268,11 +1269,17 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
   // The witness crosses PCIe in column chunks on a copy stream; the inverse transform and the
   // LDE of a chunk run while the next chunk is still in flight (values -> coefficients -> LDE are
   // per-column; only the leaf hash needs every column).
+  // The leaf hash is a sponge over the columns in order, 17 per permutation: the rate blocks of the
+  // columns that have arrived are absorbed chunk by chunk too (states wait in HBM), so that after
+  // the last chunk only its own two permutations and the tree remain.
   const double t0 = now_ms();
-  const uint32_t W = c->W, chunk = 26;
+  const uint32_t W = c->W, chunk = 34;  // two rate blocks
   const size_t n = c->n;
   const gl_t ninv = gl_inv((gl_t)n);
   Batch &b = c->wires;
+  const bool incremental = W > chunk;  // (also implies a hashed leaf: more than 3 columns)
+  if (incremental && !c->hash_state.p) HIP_TRY(c->hash_state.alloc((size_t)b.ncl * 25 * n));
+  const uint32_t full_blocks = W / 17;
   uint32_t ci = 0;
   for (uint32_t col0 = 0; col0 < W; col0 += chunk, ci++) {
     const uint32_t nc = std::min(chunk, W - col0);
@@ -1288,11 +1295,19 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
     ntt_batch(c->stream, c->plan_inv, vals, b.coeffs.p + (size_t)col0 * n, nc, 1, nullptr, ninv, false);
     ntt_batch(c->stream, c->plan_fwd, b.coeffs.p + (size_t)col0 * n, b.lde.p + (size_t)col0 * n, nc, b.ncl, c->scale.p, 1,
               false, b.cm, W);
+    if (incremental) {
+      const bool last = col0 + chunk >= W;
+      const uint32_t blk0 = col0 / 17;
+      const uint32_t nblk = last ? full_blocks - blk0 : chunk / 17;
+      hash_lde_absorb(c->stream, b.lde.p, W, c->d, b.ncl, blk0, nblk, col0 == 0, last, c->hash_state.p, b.dig.p);
+    }
   }
   const double h2d = now_ms() - t0;  // host time spent feeding PCIe (the transforms overlap with it)
   c->wires_ntt_done = true;
+  c->wires_hash_done = incremental;
   int rc = prove_impl(c, c->wires_vals.p, pis, n_pi, proof_out, proof_len, tm, h2d);
   c->wires_ntt_done = false;
+  c->wires_hash_done = false;
   return rc;
 } P2GPU_CATCH
 

@@ -300,7 +300,7 @@ NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse) {
   std::vector<P> strided;
   {
     uint32_t rem = d - b, s = b;
-    uint32_t npass = rem == 0 ? 0 : (rem <= 8 ? 1 : 2);
+    uint32_t npass = rem == 0 ? 0 : (rem <= 9 ? 1 : 2);
     for (uint32_t i = 0; i < npass; i++) {
       uint32_t a = (npass == 1) ? rem : (i == 0 ? (rem + 1) / 2 : rem / 2);
       uint32_t tb = TBMAX - a;

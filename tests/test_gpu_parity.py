@@ -45,12 +45,14 @@ def test_ifft_and_lde_match_oracle(pkg, orc, gpu, d):
     assert np.array_equal(lde, np.stack([orc.coset_lde(r, 3) for r in exp]))
 
 
-def test_three_pass_transform(pkg, orc, gpu):
-    """2^21 points: the plan splits 21 = 12 + 5 + 4 layers (two strided passes)."""
-    v = _rand((1, 1 << 21), 21)
+@pytest.mark.parametrize("d", [21, 22])
+def test_deep_transforms(pkg, orc, gpu, d):
+    """2^21 points: 12 + 9 layers (one strided pass with 64-byte runs); 2^22: 12 + 5 + 5 (two strided
+    passes) -- the plan's three-pass shape."""
+    v = _rand((1, 1 << d), d)
     coeffs = pkg.ifft_batch(v)
     assert np.array_equal(coeffs[0], orc.ntt(v[0], inverse=True))
-    lde = pkg.lde_batch(coeffs[:, : 1 << 21], 1)
+    lde = pkg.lde_batch(coeffs[:, : 1 << d], 1)
     assert np.array_equal(lde[0], orc.coset_lde(coeffs[0], 1))
 
 
@@ -207,7 +209,7 @@ def test_error_paths(pkg, gpu):
 @pytest.mark.parametrize("d,mix", [(19, "ecdsa"), (21, "arith")])
 def test_larger_configs_are_accepted(pkg, orc, gpu, d, mix):
     """BASELINE configs[3] / configs[4] sizes on ONE GPU: 2^22 LDE rows with every gate kind,
-    2^24 LDE rows (three-pass NTT, ~55 GB resident).  Property check: the verifier accepts."""
+    2^24 LDE rows (12 + 9 layer NTT, ~55 GB resident).  Property check: the verifier accepts."""
     blob, wires = pkg.make_circuit(d, mix, 2)
     cd = pkg.CircuitData(blob)
     proof = cd.prove(wires)

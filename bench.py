@@ -43,6 +43,31 @@ def pmc_traffic(kernel):
         return None, None
 
 
+VALU_PEAK = 256 * 4 * 16 * 2.4e9  # lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes/cycle x 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def issue_roofline(kernel, achieved_gbps):
+    """What actually bounds the integer kernels: VALU lane-instructions per HBM byte of
+    `kernel` from the committed rocprofv3 passes (SQ_INSTS_VALU x 64 lanes / (FETCH + WRITE bytes), same
+    command), times the live byte rate, against the chip's VALU issue peak.  None without a summary."""
+    import glob
+    sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_summary.json")))
+    pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not sq or not pm:
+        return None
+    try:
+        with open(sq[-1]) as f:
+            insts = json.load(f)["kernels"][kernel]["SQ_INSTS_VALU"] * 64.0
+        with open(pm[-1]) as f:
+            nbytes = json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+        per_byte = insts / nbytes
+        rate = per_byte * achieved_gbps * 1e9
+        return {"bound": "valu-issue", "lane_instr_per_byte": per_byte, "achieved": rate, "peak": VALU_PEAK,
+                "unit": "lane-instr/s", "frac": rate / VALU_PEAK, "source": os.path.basename(sq[-1])}
+    except Exception:
+        return None
+
+
 def cpu_baseline(pkg, d_sample, d_target, mix):
     """Oracle (CPU port of the same path) on a bounded sample: one proof at 2^d_sample gates,
     scaled linearly to the target size (NTT log factor ignored -> favours the CPU)."""
@@ -227,6 +252,7 @@ def main():
                 "avg_launch_ms": avg_ms,
                 "launches_per_proof": st["launches"] / args.steps,
                 "algorithmic_bytes_per_launch": st["bytes"] / st["launches"],
+                "issue": issue_roofline(name, gbps),
             },
             "latency_ms_single_proof": latency_ms,
             "in_flight_per_gpu": S,

@@ -1,8 +1,11 @@
-"""Regenerates tests/golden/proof_digests.json: SHA-256 of the oracle's proof bytes (minimum
-PoW witness) for small synthetic circuits, plus their transcript challenges.  These pin the
-oracle + workload generator across rounds (regression vectors); they are NOT reference outputs
--- the reference prover cannot run here.  Run from the repo root:
-    python tests/golden/gen_proof_digests.py
+"""Regenerates tests/golden/proof_digests.json (small circuits) and, with --large,
+tests/golden/proof_digests_large.json (the BASELINE sizes): SHA-256 of the oracle's proof bytes
+(minimum PoW witness) and of every prover stage inside them (tests/golden/proof_stages.py), plus the
+transcript challenges.  These pin the oracle + workload generator across rounds and let the GPU
+tests demand bit-exactness at 2^20 / 2^22 LDE rows without running the oracle on the GPU box; they
+are NOT reference outputs -- the reference prover cannot run here.  Run from the
+repo root (the --large pass takes ~10 min and ~25 GB on 8 cores):
+    python tests/golden/gen_proof_digests.py [--large]
 """
 import hashlib
 import json
@@ -13,34 +16,66 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
-CASES = [(5, "arith", 1), (6, "sha", 2), (7, "ecdsa", 3), (9, "ecdsa", 4), (10, "arith", 5)]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import mini_builder  # noqa: E402
+import proof_stages  # noqa: E402
+
+# (degree_bits, mix, seed, num_public_inputs)
+CASES = [(5, "arith", 1, 0), (6, "sha", 2, 0), (7, "ecdsa", 3, 0), (9, "ecdsa", 4, 0), (10, "arith", 5, 0)]
+# BASELINE.json configs[2] (SHA256 ~2^20 LDE rows: the bench workload, seed 1), the same size with every
+# gate kind and with public inputs (PoseidonGate), and configs[3] (EcdsaSecp256k1 ~2^22 LDE rows)
+LARGE = [(17, "sha", 1, 0), (17, "ecdsa", 1, 0), (17, "sha", 3, 4), (19, "ecdsa", 2, 0)]
+# hand-written ACIR-equivalents (BASELINE configs[0]: the fibonacci example program)
+HAND = {"fibonacci": mini_builder.fibonacci, "quadratic_example": mini_builder.quadratic_example}
+
+
+def record(oc, blob, wires, pis, meta):
+    proof, tr = oc.prove(wires, public_inputs=pis)
+    assert oc.verify(proof)
+    meta.update({
+        "blob_sha256": hashlib.sha256(blob.tobytes()).hexdigest(),
+        "wires_sha256": hashlib.sha256(wires.tobytes()).hexdigest(),
+        "constants_sigmas_cap_sha256": hashlib.sha256(oc.cap()).hexdigest(),
+        "circuit_digest": oc.digest().hex(),
+        "proof_len": len(proof),
+        "proof_sha256": hashlib.sha256(proof).hexdigest(),
+        "stages": proof_stages.stage_digests(blob, proof),
+        "betas": [int(x) for x in tr.betas[:2]], "gammas": [int(x) for x in tr.gammas[:2]],
+        "alphas": [int(x) for x in tr.alphas[:2]], "zeta": [int(x) for x in tr.zeta],
+        "pow_witness": int(tr.pow_witness),
+    })
+    return meta
+
+
+def synth_cases(pkg, orc, cases):
+    out = []
+    for d, mix, seed, npi in cases:
+        res = pkg.make_circuit(d, mix, seed, num_public_inputs=npi)
+        blob, wires = res[0], res[1]
+        pis = res[2] if npi else ()
+        oc = orc.OracleCircuit(blob)
+        out.append(record(oc, blob, wires, pis, {"degree_bits": d, "mix": mix, "seed": seed, "public_inputs": npi}))
+        oc.close()
+        print("done", d, mix, seed, npi, flush=True)
+    return out
 
 
 def main():
     entry.build()
     pkg, orc = entry.load_package(), entry.load_oracle()
-    out = []
-    for d, mix, seed in CASES:
-        blob, wires = pkg.make_circuit(d, mix, seed)
-        oc = orc.OracleCircuit(blob)
-        proof, tr = oc.prove(wires)
-        assert oc.verify(proof)
-        out.append({
-            "degree_bits": d, "mix": mix, "seed": seed,
-            "blob_sha256": hashlib.sha256(blob.tobytes()).hexdigest(),
-            "wires_sha256": hashlib.sha256(wires.tobytes()).hexdigest(),
-            "constants_sigmas_cap_sha256": hashlib.sha256(oc.cap()).hexdigest(),
-            "circuit_digest": oc.digest().hex(),
-            "proof_len": len(proof),
-            "proof_sha256": hashlib.sha256(proof).hexdigest(),
-            "betas": [int(x) for x in tr.betas[:2]], "gammas": [int(x) for x in tr.gammas[:2]],
-            "alphas": [int(x) for x in tr.alphas[:2]], "zeta": [int(x) for x in tr.zeta],
-            "pow_witness": int(tr.pow_witness),
-        })
-    path = os.path.join(ROOT, "tests", "golden", "proof_digests.json")
-    with open(path, "w") as f:
-        json.dump(out, f, indent=1)
-    print("wrote", path)
+    gold = os.path.join(ROOT, "tests", "golden")
+    if "--large" in sys.argv:
+        with open(os.path.join(gold, "proof_digests_large.json"), "w") as f:
+            json.dump(synth_cases(pkg, orc, LARGE), f, indent=1)
+        return
+    with open(os.path.join(gold, "proof_digests.json"), "w") as f:
+        json.dump(synth_cases(pkg, orc, CASES), f, indent=1)
+    hand = []
+    for name, fn in HAND.items():
+        blob, wires = fn()
+        hand.append(record(orc.OracleCircuit(blob), blob, wires, (), {"name": name}))
+    with open(os.path.join(gold, "proof_digests_hand.json"), "w") as f:
+        json.dump(hand, f, indent=1)
 
 
 if __name__ == "__main__":

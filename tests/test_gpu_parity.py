@@ -381,3 +381,57 @@ def test_coset_sharded_proof_matches_oracle(pkg, orc, gpu, world, d, mix, npi):
     for rank, proof, same in res:
         assert same, rank
         assert proof == expect, rank
+
+
+# ---- bit-exactness at the BASELINE sizes, without the oracle on the box ----------------------------
+def _gold(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def _assert_matches_gold(pkg, blob, wires, pis, g):
+    import sys
+
+    sys.path.insert(0, GOLDEN)
+    import proof_stages
+
+    assert hashlib.sha256(blob.tobytes()).hexdigest() == g["blob_sha256"]
+    assert hashlib.sha256(wires.tobytes()).hexdigest() == g["wires_sha256"]
+    cd = pkg.CircuitData(blob)
+    assert hashlib.sha256(cd.constants_sigmas_cap()).hexdigest() == g["constants_sigmas_cap_sha256"]
+    assert cd.circuit_digest().hex() == g["circuit_digest"]
+    proof = cd.prove(wires, public_inputs=pis)
+    assert proof.timings["pow_witness"] == g["pow_witness"]
+    assert len(proof) == g["proof_len"]
+    bad = proof_stages.first_difference(blob, proof.to_bytes(), g["stages"])
+    assert bad is None, f"first diverging prover stage: {bad}"
+    assert hashlib.sha256(proof.to_bytes()).hexdigest() == g["proof_sha256"]
+    cd.verify(proof)
+    cd.close()
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_baseline_size_proofs_are_bit_exact(pkg, gpu, idx):
+    """BASELINE.json configs[2] (2^20 LDE rows: `sha` = the bench workload, `ecdsa` = every gate kind,
+    `sha` + 4 public inputs = PoseidonGate rows) and configs[3] (2^22 LDE rows, every gate kind): the GPU
+    proof must equal the ORACLE's, stage by stage and as a whole.  The oracle ran in the build container
+    (tests/golden/gen_proof_digests.py --large; minutes of CPU); only SHA-256 digests travel."""
+    g = _gold("proof_digests_large.json")[idx]
+    out = pkg.make_circuit(g["degree_bits"], g["mix"], g["seed"], num_public_inputs=g["public_inputs"])
+    blob, wires = out[0], out[1]
+    pis = out[2] if g["public_inputs"] else ()
+    _assert_matches_gold(pkg, blob, wires, pis, g)
+
+
+def test_hand_written_acir_circuits_on_gpu(pkg, gpu):
+    """BASELINE.json configs[0] counterpart: the fibonacci example program as a hand-written
+    ACIR-equivalent circuit (tests/golden/mini_builder.py), proved on the GPU: same bytes as the oracle's."""
+    import sys
+
+    sys.path.insert(0, GOLDEN)
+    import mini_builder
+
+    gold = {g["name"]: g for g in _gold("proof_digests_hand.json")}
+    for name, fn in (("fibonacci", mini_builder.fibonacci), ("quadratic_example", mini_builder.quadratic_example)):
+        blob, wires = fn()
+        _assert_matches_gold(pkg, blob, wires, (), gold[name])

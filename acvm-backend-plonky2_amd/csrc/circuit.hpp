@@ -14,8 +14,10 @@
 
 namespace p2 {
 
-// thread-local message behind p2gpu_last_error()
+// thread-local message behind p2gpu_last_error() (hostcore.hip)
 void set_err(const char *fmt, ...);
+std::string last_error_copy();
+void last_error_restore(const std::string &s);
 
 // ---- host transcript (iop/challenger.rs, Challenger<F, KeccakHash<25>>) ----
 struct Challenger {
@@ -177,6 +179,7 @@ struct CircuitState {
 struct p2gpu_circuit : p2::CircuitState {};
 
 namespace p2 {
+extern void (*g_circuit_release)(p2gpu_circuit *);  // hostcore.hip; set by prover.hip
 // blob header + gate table + (optional) cap + k_is -> the host-side fields of the handle; leaves
 // *off at the constants table.  Used by p2gpu_circuit_create and p2gpu_verifier_create.
 int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off, const uint8_t **cap_in);

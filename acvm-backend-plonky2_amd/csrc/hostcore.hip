@@ -1,0 +1,236 @@
+// hostcore.hip -- the kernel-free core of libp2gpu: error text, circuit-blob parsing and validation,
+// handle getters and destruction.  Everything here (and verify.hip, proofio.hip) is plain host code
+// that never launches a kernel, so the three files also build WITHOUT device code under
+// -fsanitize=address,undefined (`make asan` -> libp2gpu_host_asan.so) for the fuzz tests: these are
+// the parsers that read untrusted bytes on machines with no GPU (the reference's `verify` action,
+// plonky2-backend/src/actions/verify_action.rs:11-17, reader noir_and_plonky2_serialization.rs:16-33).
+#include "circuit.hpp"
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+using namespace p2;
+
+namespace {
+thread_local std::string g_err;
+}  // namespace
+namespace p2 {
+void set_err(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+std::string last_error_copy() { return g_err; }
+void last_error_restore(const std::string &s) { g_err = s; }
+// set by prover.hip (the TU that owns device memory): releases a prover handle's device state
+void (*g_circuit_release)(p2gpu_circuit *) = nullptr;
+}  // namespace p2
+
+namespace {
+// Per-kind parameter ranges and wire/constant bounds of one gate-table entry.  Runs BEFORE anything
+// derives a size or an index from the parameters: the blob is untrusted input for the CPU-only
+// verifier (p2gpu_verifier_create) as much as for the prover, and the same descriptors drive the
+// indices of the quotient / witness kernels.  Returns nullptr when the entry is acceptable.
+const char *gate_validate(uint32_t kind, const uint32_t p[4], uint32_t W, uint32_t gate_consts, uint64_t *wires_used,
+                          uint32_t *consts_used) {
+  uint64_t w = 0;
+  uint32_t k = 0;
+  auto in = [](uint32_t v, uint32_t lo, uint32_t hi) { return v >= lo && v <= hi; };
+  switch (kind) {
+  case G_NOOP: break;
+  case G_CONSTANT:
+    if (!in(p[0], 1, 4096)) return "ConstantGate: num_consts out of range";
+    w = p[0]; k = p[0];
+    break;
+  case G_PUBLIC_INPUT: w = 4; break;
+  case G_ARITHMETIC:
+    if (!in(p[0], 1, 1024)) return "ArithmeticGate: num_ops out of range";
+    w = 4ull * p[0]; k = 2;
+    break;
+  case G_BASE_SUM:
+    if (!in(p[0], 2, 8)) return "BaseSumGate: base must be 2..8";
+    if (!in(p[1], 1, 64)) return "BaseSumGate: num_limbs must be 1..64";
+    w = 1ull + p[1];
+    break;
+  case G_RANDOM_ACCESS:
+    if (!in(p[0], 1, 6)) return "RandomAccessGate: bits must be 1..6";
+    if (!in(p[1], 1, 1024)) return "RandomAccessGate: num_copies out of range";
+    if (p[2] > 2) return "RandomAccessGate: more than 2 extra constants";
+    w = (2ull + (1ull << p[0])) * p[1] + p[2] + (uint64_t)p[1] * p[0]; k = p[2];
+    break;
+  case G_POSEIDON: w = 135; break;
+  case G_U32_ARITHMETIC:
+    if (!in(p[0], 1, 1024)) return "U32ArithmeticGate: num_ops out of range";
+    w = 38ull * p[0];
+    break;
+  case G_U32_ADD_MANY:
+    if (!in(p[0], 1, 16)) return "U32AddManyGate: num_addends must be 1..16";
+    if (!in(p[1], 1, 1024)) return "U32AddManyGate: num_ops out of range";
+    w = ((uint64_t)p[0] + 3 + 18) * p[1];
+    break;
+  case G_U32_SUBTRACTION:
+    if (!in(p[0], 1, 1024)) return "U32SubtractionGate: num_ops out of range";
+    w = 21ull * p[0];
+    break;
+  case G_U32_RANGE_CHECK:
+    if (!in(p[0], 1, 1024)) return "U32RangeCheckGate: num_input_limbs out of range";
+    w = 17ull * p[0];
+    break;
+  case G_COMPARISON: {
+    if (!in(p[0], 1, 64) || !in(p[1], 1, 64)) return "ComparisonGate: num_bits / num_chunks must be 1..64";
+    const uint32_t cb = (p[0] + p[1] - 1) / p[1];
+    if (cb > 4) return "ComparisonGate: chunk_bits > 4 unsupported";
+    w = 4ull + 5ull * p[1] + cb + 1;
+    break;
+  }
+  default: return "unsupported gate kind in blob";
+  }
+  if (w > W) return "gate needs more wires than the circuit has";
+  if (k > gate_consts) return "gate needs more constants than the circuit has";
+  *wires_used = w;
+  *consts_used = k;
+  return nullptr;
+}
+
+uint32_t gate_num_constraints(uint32_t kind, const uint32_t p[4]) {
+  switch (kind) {
+  case G_NOOP: return 0;
+  case G_CONSTANT: return p[0];
+  case G_PUBLIC_INPUT: return 4;
+  case G_ARITHMETIC: return p[0];
+  case G_BASE_SUM: return 1 + p[1];
+  case G_RANDOM_ACCESS: return p[1] * (p[0] + 2) + p[2];
+  case G_POSEIDON: return 123;
+  case G_U32_ARITHMETIC: return p[0] * 36;
+  case G_U32_ADD_MANY: return p[1] * 21;
+  case G_U32_SUBTRACTION: return p[0] * 19;
+  case G_U32_RANGE_CHECK: return p[0] * 17;
+  case G_COMPARISON: return 6 + 5 * p[1] + (p[0] + p[1] - 1) / p[1];
+  }
+  return 0;
+}
+}  // namespace
+
+namespace p2 {
+int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off_out, const uint8_t **cap_in) {
+  if (len < 256) { set_err("blob too short"); return P2GPU_E_BLOB; }
+  uint32_t h[64];
+  memcpy(h, blob, sizeof h);
+  if (h[0] != 0x43473250u || h[1] != 1) { set_err("bad blob magic/version"); return P2GPU_E_BLOB; }
+  c->d = h[2]; c->W = h[3]; c->R = h[4]; c->NC = h[5]; c->num_selectors = h[6]; c->K = h[7]; c->QF = h[8];
+  c->rate_bits = h[9]; c->cap_h = h[10]; c->pow_bits = h[11]; c->num_queries = h[12]; c->n_steps = h[13];
+  for (int i = 0; i < 8; i++) c->arity[i] = h[14 + i];
+  const uint32_t hasher = h[22];
+  c->num_gates = h[23]; c->num_pi = h[24]; c->flags = h[25]; c->PP = h[26];
+  auto fail = [&](int rc, const char *msg) {
+    set_err("%s", msg);
+    return rc;
+  };
+  if (hasher != 0) return fail(P2GPU_E_BLOB, "unsupported hasher (only KeccakHash<25>)");
+  if (c->d < 1 || c->d > 24 || c->K < 1 || c->K > 2 || c->rate_bits < 1 || c->rate_bits > 3 || c->cap_h < c->rate_bits ||
+      c->cap_h > c->rate_bits + c->d || c->n_steps > 8 || c->R > MAX_ROUTED || c->QF == 0 || c->num_gates > MAX_GATES ||
+      c->num_queries > 64 || c->W < c->R || (1u << c->rate_bits) != c->QF || c->pow_bits > 32 || c->W > 4096 ||
+      c->NC > 4096 || c->num_selectors > c->NC || c->num_selectors == 0 || c->num_pi > (1u << 20) || c->num_queries == 0)
+    return fail(P2GPU_E_BLOB, "unsupported circuit parameters");
+  c->n = (size_t)1 << c->d;
+  c->N = c->n << c->rate_bits;
+  c->C = 1u << c->rate_bits;
+  c->nchunks = (c->R + c->QF - 1) / c->QF;
+  if (c->nchunks > 16 || c->PP != c->nchunks - 1) return fail(P2GPU_E_BLOB, "unsupported circuit parameters");
+  {
+    // fri/reduction_strategies.rs: every step must leave at least the cap below it
+    uint32_t ds = c->d;
+    for (uint32_t s = 0; s < c->n_steps; s++) {
+      const uint32_t ab = c->arity[s];
+      if (ab < 1 || ab > MAX_ARITY_BITS || ds < ab || ds + c->rate_bits - ab < c->cap_h) return fail(P2GPU_E_BLOB, "unsupported FRI reduction arity");
+      ds -= ab;
+    }
+  }
+  size_t off = 256;
+  if (len < off + (size_t)c->num_gates * 48) return fail(P2GPU_E_BLOB, "blob truncated (gate table)");
+  c->max_gate_constraints = 0;
+  c->gates.clear();
+  for (uint32_t i = 0; i < c->num_gates; i++) {
+    uint32_t g[12];
+    memcpy(g, blob + off, sizeof g);
+    off += sizeof g;
+    GateDesc G;
+    G.kind = g[0];
+    memcpy(G.p, &g[1], 16);
+    G.sel_index = g[5]; G.group_start = g[6]; G.group_end = g[7]; G.num_constraints = g[8]; G.degree = g[9];
+    G.num_constants = g[10]; G.pad = 0;
+    if (G.kind >= G_KIND_COUNT) return fail(P2GPU_E_BLOB, "unsupported gate kind in blob");
+    uint64_t wires_used = 0;
+    uint32_t consts_used = 0;
+    if (const char *why = gate_validate(G.kind, G.p, c->W, c->NC - c->num_selectors, &wires_used, &consts_used))
+      return fail(P2GPU_E_BLOB, why);
+    if (G.num_constraints != gate_num_constraints(G.kind, G.p) || G.num_constraints > MAX_GATE_CONSTRAINTS)
+      return fail(P2GPU_E_BLOB, "gate constraint count mismatch");
+    if (G.num_constants > c->NC - c->num_selectors || G.num_constants < consts_used || G.degree > 9)
+      return fail(P2GPU_E_BLOB, "bad gate constant count / degree");
+    if (G.sel_index >= c->num_selectors || G.group_end > c->num_gates || G.group_start > i || i >= G.group_end)
+      return fail(P2GPU_E_BLOB, "bad selector info");
+    c->max_gate_constraints = std::max(c->max_gate_constraints, G.num_constraints);
+    c->gates.push_back(G);
+  }
+  *cap_in = nullptr;
+  if (c->flags & 2) {
+    if (len < off + ((size_t)32 << c->cap_h)) return fail(P2GPU_E_BLOB, "blob truncated (cap)");
+    *cap_in = blob + off;
+    off += (size_t)32 << c->cap_h;
+  }
+  if (len < off + 8 * (size_t)c->R) return fail(P2GPU_E_BLOB, "blob truncated (k_is)");
+  c->k_is.resize(c->R);
+  memcpy(c->k_is.data(), blob + off, 8 * (size_t)c->R);
+  off += 8 * (size_t)c->R;
+  if (c->flags & 1) {
+    memset(&c->circuit_digest, 0, sizeof(dig_t));
+    memcpy(c->circuit_digest.w, &h[32], 25);
+  }
+  poseidon_round_constants_host(c->poseidon_rc);
+  *off_out = off;
+  return P2GPU_OK;
+}
+}  // namespace p2
+
+extern "C" {
+
+const char *p2gpu_last_error(void) { return g_err.c_str(); }
+
+size_t p2gpu_proof_size_bound(const p2gpu_circuit *c) {
+  if (!c) return 0;
+  const size_t ncap = (size_t)1 << c->cap_h;
+  const size_t ncs = c->NC + c->R, nzp = c->K * (1 + c->PP), nq = c->K * c->QF;
+  size_t sz = 3 * ncap * 25 + 16 * (ncs + c->W + nzp + nq + c->K) + c->n_steps * ncap * 25;
+  size_t per_q = 8 * (ncs + c->W + nzp + nq) + 4 * (1 + 25 * (size_t)(c->d + c->rate_bits));
+  for (uint32_t s = 0; s < c->n_steps; s++) per_q += (16u << c->arity[s]) + 1 + 25 * (size_t)(c->d + c->rate_bits);
+  size_t n_final = c->n;
+  for (uint32_t s = 0; s < c->n_steps; s++) n_final >>= c->arity[s];
+  sz += per_q * c->num_queries + 16 * n_final + 8 + 8 * c->num_pi + 64;
+  return sz;
+}
+
+void p2gpu_circuit_destroy(p2gpu_circuit *c) {
+  if (!c) return;
+  if (c->device >= 0 && g_circuit_release) g_circuit_release(c);  // a verifier-only handle owns nothing on a device
+  delete c;
+}
+
+int p2gpu_circuit_cap(const p2gpu_circuit *c, uint8_t *out) {
+  if (!c || !out) return P2GPU_E_ARG;
+  for (size_t i = 0; i < c->cs.cap.size(); i++) memcpy(out + 25 * i, c->cs.cap[i].w, 25);
+  return P2GPU_OK;
+}
+int p2gpu_circuit_device(const p2gpu_circuit *c) { return c ? c->device : P2GPU_E_ARG; }
+int p2gpu_circuit_digest(const p2gpu_circuit *c, uint8_t out[25]) {
+  if (!c || !out) return P2GPU_E_ARG;
+  memcpy(out, c->circuit_digest.w, 25);
+  return P2GPU_OK;
+}
+
+}  // extern "C"

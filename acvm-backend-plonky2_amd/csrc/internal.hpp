@@ -9,6 +9,8 @@
 namespace p2 {
 
 constexpr int MAX_GATES = 64;
+constexpr uint32_t MAX_GATE_CONSTRAINTS = 4096;  // per gate; every supported kind at W <= 4096 stays below
+constexpr uint32_t MAX_ARITY_BITS = 4;  // FRI reduction arity 2^4 at most: one limit for circuit_parse, prover and verifier
 constexpr int MAX_CHALLENGES = 2;
 constexpr int MAX_ROUTED = 128;
 

@@ -21,19 +21,8 @@
 
 using namespace p2;
 
-namespace {
-thread_local std::string g_err;
-}  // namespace
 namespace p2 {
 thread_local Prof *g_prof = nullptr;
-void set_err(const char *fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  g_err = buf;
-}
 }  // namespace p2
 namespace {
 #define HIP_TRY(expr)                                                                          \
@@ -723,6 +712,16 @@ void circuit_release(p2gpu_circuit *c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
+// hostcore.hip's p2gpu_circuit_destroy calls this for prover handles (it has no HIP code of its own)
+void release_for_destroy(p2gpu_circuit *c) {
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  circuit_release(c);
+}
+struct ReleaseHook {
+  ReleaseHook() { p2::g_circuit_release = release_for_destroy; }
+} g_release_hook;
+
 int g_device = -1;
 
 int ensure_device() {
@@ -739,99 +738,10 @@ int ensure_device() {
   return 0;
 }
 
-uint32_t gate_num_constraints(uint32_t kind, const uint32_t p[4]) {
-  switch (kind) {
-  case G_NOOP: return 0;
-  case G_CONSTANT: return p[0];
-  case G_PUBLIC_INPUT: return 4;
-  case G_ARITHMETIC: return p[0];
-  case G_BASE_SUM: return 1 + p[1];
-  case G_RANDOM_ACCESS: return p[1] * (p[0] + 2) + p[2];
-  case G_POSEIDON: return 123;
-  case G_U32_ARITHMETIC: return p[0] * 36;
-  case G_U32_ADD_MANY: return p[1] * 21;
-  case G_U32_SUBTRACTION: return p[0] * 19;
-  case G_U32_RANGE_CHECK: return p[0] * 17;
-  case G_COMPARISON: return 6 + 5 * p[1] + (p[0] + p[1] - 1) / p[1];
-  }
-  return 0;
-}
 
 }  // namespace
 
 namespace p2 {
-int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off_out, const uint8_t **cap_in) {
-  if (len < 256) { set_err("blob too short"); return P2GPU_E_BLOB; }
-  uint32_t h[64];
-  memcpy(h, blob, sizeof h);
-  if (h[0] != 0x43473250u || h[1] != 1) { set_err("bad blob magic/version"); return P2GPU_E_BLOB; }
-  c->d = h[2]; c->W = h[3]; c->R = h[4]; c->NC = h[5]; c->num_selectors = h[6]; c->K = h[7]; c->QF = h[8];
-  c->rate_bits = h[9]; c->cap_h = h[10]; c->pow_bits = h[11]; c->num_queries = h[12]; c->n_steps = h[13];
-  for (int i = 0; i < 8; i++) c->arity[i] = h[14 + i];
-  const uint32_t hasher = h[22];
-  c->num_gates = h[23]; c->num_pi = h[24]; c->flags = h[25]; c->PP = h[26];
-  auto fail = [&](int rc, const char *msg) {
-    set_err("%s", msg);
-    return rc;
-  };
-  if (hasher != 0) return fail(P2GPU_E_BLOB, "unsupported hasher (only KeccakHash<25>)");
-  if (c->d < 1 || c->d > 24 || c->K < 1 || c->K > 2 || c->rate_bits < 1 || c->rate_bits > 3 || c->cap_h < c->rate_bits ||
-      c->cap_h > c->rate_bits + c->d || c->n_steps > 8 || c->R > MAX_ROUTED || c->QF == 0 || c->num_gates > MAX_GATES ||
-      c->num_queries > 64 || c->W < c->R || (1u << c->rate_bits) != c->QF || c->pow_bits > 32 || c->W > 4096 ||
-      c->NC > 4096 || c->num_selectors > c->NC || c->num_selectors == 0 || c->num_pi > (1u << 20) || c->num_queries == 0)
-    return fail(P2GPU_E_BLOB, "unsupported circuit parameters");
-  c->n = (size_t)1 << c->d;
-  c->N = c->n << c->rate_bits;
-  c->C = 1u << c->rate_bits;
-  c->nchunks = (c->R + c->QF - 1) / c->QF;
-  if (c->nchunks > 16 || c->PP != c->nchunks - 1) return fail(P2GPU_E_BLOB, "unsupported circuit parameters");
-  {
-    // fri/reduction_strategies.rs: every step must leave at least the cap below it
-    uint32_t ds = c->d;
-    for (uint32_t s = 0; s < c->n_steps; s++) {
-      const uint32_t ab = c->arity[s];
-      if (ab < 1 || ab > 4 || ds < ab || ds + c->rate_bits - ab < c->cap_h) return fail(P2GPU_E_BLOB, "unsupported FRI reduction arity");
-      ds -= ab;
-    }
-  }
-  size_t off = 256;
-  if (len < off + (size_t)c->num_gates * 48) return fail(P2GPU_E_BLOB, "blob truncated (gate table)");
-  c->max_gate_constraints = 0;
-  c->gates.clear();
-  for (uint32_t i = 0; i < c->num_gates; i++) {
-    uint32_t g[12];
-    memcpy(g, blob + off, sizeof g);
-    off += sizeof g;
-    GateDesc G;
-    G.kind = g[0];
-    memcpy(G.p, &g[1], 16);
-    G.sel_index = g[5]; G.group_start = g[6]; G.group_end = g[7]; G.num_constraints = g[8]; G.degree = g[9];
-    G.num_constants = g[10]; G.pad = 0;
-    if (G.kind >= G_KIND_COUNT) return fail(P2GPU_E_BLOB, "unsupported gate kind in blob");
-    if (G.num_constraints != gate_num_constraints(G.kind, G.p)) return fail(P2GPU_E_BLOB, "gate constraint count mismatch");
-    if (G.kind == G_RANDOM_ACCESS && G.p[0] > 6) return fail(P2GPU_E_BLOB, "RandomAccessGate bits > 6 unsupported");
-    if (G.sel_index >= c->num_selectors || G.group_end > c->num_gates) return fail(P2GPU_E_BLOB, "bad selector info");
-    c->max_gate_constraints = std::max(c->max_gate_constraints, G.num_constraints);
-    c->gates.push_back(G);
-  }
-  *cap_in = nullptr;
-  if (c->flags & 2) {
-    if (len < off + ((size_t)32 << c->cap_h)) return fail(P2GPU_E_BLOB, "blob truncated (cap)");
-    *cap_in = blob + off;
-    off += (size_t)32 << c->cap_h;
-  }
-  if (len < off + 8 * (size_t)c->R) return fail(P2GPU_E_BLOB, "blob truncated (k_is)");
-  c->k_is.resize(c->R);
-  memcpy(c->k_is.data(), blob + off, 8 * (size_t)c->R);
-  off += 8 * (size_t)c->R;
-  if (c->flags & 1) {
-    memset(&c->circuit_digest, 0, sizeof(dig_t));
-    memcpy(c->circuit_digest.w, &h[32], 25);
-  }
-  poseidon_round_constants_host(c->poseidon_rc);
-  *off_out = off;
-  return P2GPU_OK;
-}
 }  // namespace p2
 
 // scratch allocations of the stage-level operators
@@ -855,7 +765,6 @@ struct Scratch {
 
 extern "C" {
 
-const char *p2gpu_last_error(void) { return g_err.c_str(); }
 
 int p2gpu_init(const int *device_ids, int n_devices) {
   int cnt = 0;
@@ -863,6 +772,12 @@ int p2gpu_init(const int *device_ids, int n_devices) {
   if (e != hipSuccess || cnt == 0) {
     set_err("no HIP device available (%s); libp2gpu has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
     return P2GPU_E_DEVICE;
+  }
+  // one process per GPU: exactly one device per process; more than one id is a caller
+  // bug, not something to ignore silently
+  if (device_ids && n_devices > 1) {
+    set_err("p2gpu_init: %d device ids given; this library runs one process per GPU (pass one id)", n_devices);
+    return P2GPU_E_ARG;
   }
   int dev = (device_ids && n_devices > 0) ? device_ids[0] : 0;
   if (dev < 0 || dev >= cnt) {
@@ -884,17 +799,6 @@ int p2gpu_device_info(char *name_out, size_t name_cap, int *cu_count, size_t *hb
   return P2GPU_OK;
 }
 
-size_t p2gpu_proof_size_bound(const p2gpu_circuit *c) {
-  const size_t ncap = (size_t)1 << c->cap_h;
-  const size_t ncs = c->NC + c->R, nzp = c->K * (1 + c->PP), nq = c->K * c->QF;
-  size_t sz = 3 * ncap * 25 + 16 * (ncs + c->W + nzp + nq + c->K) + c->n_steps * ncap * 25;
-  size_t per_q = 8 * (ncs + c->W + nzp + nq) + 4 * (1 + 25 * (size_t)(c->d + c->rate_bits));
-  for (uint32_t s = 0; s < c->n_steps; s++) per_q += (16u << c->arity[s]) + 1 + 25 * (size_t)(c->d + c->rate_bits);
-  size_t n_final = c->n;
-  for (uint32_t s = 0; s < c->n_steps; s++) n_final >>= c->arity[s];
-  sz += per_q * c->num_queries + 16 * n_final + 8 + 8 * c->num_pi + 64;
-  return sz;
-}
 
 int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c) try {
   if (!blob || !out_c) return P2GPU_E_ARG;
@@ -952,10 +856,10 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   };
 #define CK(e, what)                                   \
   if (H((e), what)) {                                 \
-    std::string keep = g_err;                         \
+    std::string keep = last_error_copy();                         \
     circuit_release(c);                               \
     delete c;                                         \
-    g_err = keep;                                     \
+    last_error_restore(keep);                                     \
     return P2GPU_E_DEVICE;                            \
   }
   CK(hipSetDevice(c->device), "hipSetDevice");
@@ -1032,10 +936,10 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   }
   mark("sigma/constant uploads, row->gate");
   if (batch_alloc(c, c->cs, ncs) || batch_alloc(c, c->wires, c->W) || batch_alloc(c, c->zp, nzp) || batch_alloc(c, c->quot, nq)) {
-    std::string keep = g_err;
+    std::string keep = last_error_copy();
     circuit_release(c);
     delete c;
-    g_err = keep;
+    last_error_restore(keep);
     return P2GPU_E_DEVICE;
   }
   CK(c->wires_vals.alloc((size_t)c->W * n), "alloc wires");
@@ -1070,10 +974,10 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
           return fail(P2GPU_E_BLOB, "unsupported FRI reduction arity");
         }
         if (tree_alloc(c->fri_trees[s], C, ((size_t)1 << ds) >> ab, cap_per)) {
-          std::string keep = g_err;
+          std::string keep = last_error_copy();
           circuit_release(c);
           delete c;
-          g_err = keep;
+          last_error_restore(keep);
           return P2GPU_E_DEVICE;
         }
         gather_words += (2u << ab) + 4 * (size_t)(ds + c->rate_bits);
@@ -1099,10 +1003,10 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
       ntt_batch(st, c->plan_inv, stage, c->cs.coeffs.p, ncs, 1, nullptr, ninv, false);
     }
     if (int rc = batch_commit_from_coeffs(c, c->cs)) {
-      std::string keep = g_err;
+      std::string keep = last_error_copy();
       circuit_release(c);
       delete c;
-      g_err = keep;
+      last_error_restore(keep);
       return rc;
     }
   }
@@ -1135,26 +1039,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   return P2GPU_OK;
 } P2GPU_CATCH
 
-void p2gpu_circuit_destroy(p2gpu_circuit *c) {
-  if (!c) return;
-  if (c->device >= 0) {  // a verifier-only handle owns nothing on a device
-    (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    circuit_release(c);
-  }
-  delete c;
-}
 
-int p2gpu_circuit_cap(const p2gpu_circuit *c, uint8_t *out) {
-  if (!c || !out) return P2GPU_E_ARG;
-  for (size_t i = 0; i < c->cs.cap.size(); i++) memcpy(out + 25 * i, c->cs.cap[i].w, 25);
-  return P2GPU_OK;
-}
-int p2gpu_circuit_digest(const p2gpu_circuit *c, uint8_t out[25]) {
-  if (!c || !out) return P2GPU_E_ARG;
-  memcpy(out, c->circuit_digest.w, 25);
-  return P2GPU_OK;
-}
 
 int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
   if (!c || !key) return P2GPU_E_ARG;
@@ -1278,7 +1163,10 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
   const gl_t ninv = gl_inv((gl_t)n);
   Batch &b = c->wires;
   const bool incremental = W > chunk;  // (also implies a hashed leaf: more than 3 columns)
-  if (incremental && !c->hash_state.p) HIP_TRY(c->hash_state.alloc((size_t)b.ncl * 25 * n));
+  if (incremental && c->hash_state.count < (size_t)b.ncl * 25 * n) {  // also after set_shard(world 1 again): more local cosets
+    c->hash_state.release();
+    HIP_TRY(c->hash_state.alloc((size_t)b.ncl * 25 * n));
+  }
   const uint32_t full_blocks = W / 17;
   uint32_t ci = 0;
   for (uint32_t col0 = 0; col0 < W; col0 += chunk, ci++) {

@@ -198,7 +198,7 @@ int p2gpu_verify(const p2gpu_circuit *c, const uint8_t *proof, size_t len) try {
     unsigned lg = lgN;
     for (uint32_t s = 0; s < c->n_steps; s++) {
       const unsigned ab = c->arity[s];
-      if (ab < 1 || ab > 6 || lg < ab + c->cap_h || (final_len >> ab) == 0) return reject("bad reduction arity in circuit");
+      if (ab < 1 || ab > MAX_ARITY_BITS || lg < ab + c->cap_h || (final_len >> ab) == 0) return reject("bad reduction arity in circuit");
       lg -= ab;
       final_len >>= ab;
       query_bytes += ((size_t)16 << ab) + 1 + 25 * (size_t)(lg - c->cap_h);
@@ -211,7 +211,7 @@ int p2gpu_verify(const p2gpu_circuit *c, const uint8_t *proof, size_t len) try {
   in.at = tail_at;
   std::vector<ext_t> final_poly(final_len);
   for (auto &e : final_poly) e = in.ext();
-  const uint64_t pow_witness = in.u64();
+  const uint64_t pow_witness = in.felt();  // canonical, like every other field element (upstream reduces it; a non-canonical encoding is not a second valid proof here)
   std::vector<gl_t> pis(c->num_pi);
   for (auto &v : pis) v = in.felt();
   if (!in.ok) return reject("non-canonical field element in final polynomial / public inputs");
@@ -295,7 +295,7 @@ int p2gpu_verify(const p2gpu_circuit *c, const uint8_t *proof, size_t len) try {
     for (uint32_t s = 0; s < c->n_steps; s++) {
       const unsigned ab = c->arity[s];
       const uint32_t a = 1u << ab;
-      ext_t y_leaf[64], y_nat[64];
+      ext_t y_leaf[1 << MAX_ARITY_BITS], y_nat[1 << MAX_ARITY_BITS];
       gl_t flat[128];
       for (uint32_t i = 0; i < a; i++) {
         y_leaf[i] = in.ext();

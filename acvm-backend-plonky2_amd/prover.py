@@ -83,6 +83,7 @@ def load_library():
     lib.p2gpu_circuit_digest.argtypes = [vp, u8p]
     lib.p2gpu_proof_size_bound.argtypes = [vp]
     lib.p2gpu_proof_size_bound.restype = sz
+    lib.p2gpu_circuit_device.argtypes = [vp]
     lib.p2gpu_prove.argtypes = [vp, vp, vp, ctypes.c_uint32, u8p, ctypes.POINTER(sz), ctypes.POINTER(_Timings)]
     lib.p2gpu_prove_dev.argtypes = lib.p2gpu_prove.argtypes
     lib.p2gpu_prove_routed.argtypes = lib.p2gpu_prove.argtypes
@@ -151,6 +152,7 @@ class CircuitData:
         hdr = self._blob[:256].view(np.uint32)
         self.degree_bits = int(hdr[2])
         self.num_wires = int(hdr[3])
+        self.num_routed_wires = int(hdr[4])
         self.rate_bits = int(hdr[9])
         self.cap_height = int(hdr[10])
         self.num_public_inputs = int(hdr[24])
@@ -175,6 +177,10 @@ class CircuitData:
         out = np.zeros(25, dtype=np.uint8)
         _check(self._lib.p2gpu_circuit_digest(self._h, out.ctypes.data))
         return out.tobytes()
+
+    def device_index(self):
+        """HIP device the handle's buffers and streams live on."""
+        return int(self._lib.p2gpu_circuit_device(self._h))
 
     def set(self, key, value):
         _check(self._lib.p2gpu_circuit_set(self._h, key.encode(), ctypes.c_uint64(value)))
@@ -237,6 +243,8 @@ class CircuitData:
         if hasattr(wires, "data_ptr") and getattr(wires, "is_cuda", False):
             if wires.numel() != expect or wires.element_size() != 8 or not wires.is_contiguous():
                 raise P2GpuError(-7, "wires tensor must be contiguous int64/uint64 [num_wires][degree]")
+            if wires.device.index != self.device_index():
+                raise P2GpuError(-7, f"wires tensor lives on cuda:{wires.device.index}, the circuit on cuda:{self.device_index()}")
             rc = self._lib.p2gpu_prove_dev(self._h, ctypes.c_void_p(wires.data_ptr()), pis.ctypes.data, len(pis),
                                            out.ctypes.data, ctypes.byref(plen), ctypes.byref(tm))
         else:
@@ -263,6 +271,8 @@ class CircuitData:
         columns are derived on the GPU by the row-local generators."""
         pis = _u64(np.array(list(public_inputs), dtype=np.uint64))
         r = _u64(routed)
+        if r.size != self.num_routed_wires * self.degree:
+            raise P2GpuError(-7, f"routed must be [num_routed_wires={self.num_routed_wires}][degree={self.degree}]")
         out = np.zeros(self._bound, dtype=np.uint8)
         plen = ctypes.c_size_t(out.nbytes)
         tm = _Timings()

@@ -56,6 +56,22 @@ int main(int argc, char **argv) {
     fprintf(stderr, "cannot read inputs\n");
     return 1;
   }
+  /* the wire matrix must have exactly the shape the blob header announces (p2gpu_prove reads
+   * 8 * cols * 2^d bytes from this pointer): header words [2] degree_bits, [3] num_wires, [4] num_routed, [24] #PI */
+  if (blob_len >= 256) {
+    uint32_t h[64];
+    memcpy(h, blob, sizeof h);
+    const uint64_t cols = routed ? h[4] : h[3];
+    if (h[2] < 40 && wires_len != 8ull * cols * (1ull << h[2])) {
+      fprintf(stderr, "%s: %zu bytes, but the circuit needs %s[%u][2^%u] u64 = %llu bytes\n", pos[1], wires_len,
+              routed ? "routed" : "wires", (unsigned)cols, h[2], (unsigned long long)(8ull * cols * (1ull << h[2])));
+      return 1;
+    }
+    if (pi_len != 8ull * h[24]) {
+      fprintf(stderr, "public inputs: %zu bytes, the circuit has %u public inputs\n", pi_len, h[24]);
+      return 1;
+    }
+  }
   p2gpu_circuit *c = NULL;
   int rc = p2gpu_circuit_create(blob, blob_len, &c);
   if (rc) {

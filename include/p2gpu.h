@@ -95,7 +95,7 @@ typedef struct {
   uint64_t pow_witness;
 } p2gpu_timings;
 
-/* Select devices for this process (one process per GPU: pass one id).
+/* Select the device of this process (one process per GPU: pass exactly one id; more is P2GPU_E_ARG).
  * device_ids may be NULL for {current device}. */
 int p2gpu_init(const int *device_ids, int n_devices);
 
@@ -104,6 +104,8 @@ void p2gpu_circuit_destroy(p2gpu_circuit *c);
 /* 2^cap_height x 25 bytes */
 int p2gpu_circuit_cap(const p2gpu_circuit *c, uint8_t *out);
 int p2gpu_circuit_digest(const p2gpu_circuit *c, uint8_t out[25]);
+/* HIP device index the handle lives on (< 0: verifier-only handle / bad argument) */
+int p2gpu_circuit_device(const p2gpu_circuit *c);
 /* upper bound of the proof size in bytes for this circuit */
 size_t p2gpu_proof_size_bound(const p2gpu_circuit *c);
 

@@ -30,7 +30,12 @@ def test_library_is_in_tree_and_gfx950(pkg):
     assert path.startswith(ROOT) and os.path.exists(path)
     data = open(path, "rb").read()
     assert b"gfx950" in data  # the code object is built for MI355X only
-    assert b"oracle" not in data.lower() or b"liboracle" not in data  # the product never links the checker
+    # the product never links, loads or names the checker: no oracle symbol / file name in the binary
+    for needle in (b"liboracle", b"pyoracle", b"orc_prove", b"orc_verify", b"orc_circuit"):
+        assert needle not in data, needle
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+    assert "oracle" not in needed.lower()
 
 
 def test_product_sources_do_not_reference_the_oracle():

@@ -58,7 +58,9 @@ int main(int argc, char **argv) {
   }
   /* the wire matrix must have exactly the shape the blob header announces (p2gpu_prove reads
    * 8 * cols * 2^d bytes from this pointer): header words [2] degree_bits, [3] num_wires, [4] num_routed, [24] #PI */
-  if (blob_len >= 256) {
+  uint32_t magic = 0;
+  if (blob_len >= 4) memcpy(&magic, blob, 4);
+  if (blob_len >= 256 && magic == 0x43473250u) { /* anything else: let p2gpu_circuit_create report it */
     uint32_t h[64];
     memcpy(h, blob, sizeof h);
     const uint64_t cols = routed ? h[4] : h[3];

@@ -7,12 +7,18 @@ bytes back on the host (the boundary of p2gpu_prove_dev).  N > 1: one process pe
 (torch.distributed / RCCL), every rank proves its own independent proofs (replicas, weak
 scaling, no data-path collective); time = max over ranks between two barriers.
 
-Prints ONE JSON line on rank 0 (see the round contract): metric/value/unit, ms_per_step,
-`roofline` for the dominant kernel (HIP-event time measured inside the library on its launch
-stream over the timed region, algorithmic bytes from DESIGN.md) and `cpu_baseline` (the
-oracle = CPU port, timed on this host's cores on a bounded sample; N = 1 only).
+The timed region runs the production path only: no per-launch events, no oracle.  After it, in
+the same process, separate passes collect what the JSON line reports beside `value`:
+  * `host_witness`: the same proofs through p2gpu_prove (witness in host RAM, the 245 MB H2D inside
+    the call) -- SURVEY.md 8(d)'s boundary-to-boundary number, never `value`;
+  * `pipelined`: three proofs in flight on one GPU (separate handles / streams);
+  * `roofline` + `kernel_ms_per_proof`: per-launch HIP events on the library's launch stream
+    (`profile` knob) over a few extra proofs;
+  * `cpu_baseline` (N = 1): the oracle = CPU port, on THIS workload, all host cores, unscaled.
+Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -24,70 +30,127 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md; 6.29 TB/s is what a float4 copy reaches)
+# VALU issue ceiling measured on this chip (profiles/r02_ubench.txt, scratch/ubench/issue.hip): v_fma_f32,
+# v_xor_b32, v_bitop3_b32, v_add_co/v_addc_co, v_cmp+v_cndmask all saturate at 38-46 T lane-instr/s with 4-8
+# waves per SIMD (v_mad_u64_u32: 26-31 T); 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T is used as
+# the round number for "what one instruction per lane costs".
+VALU_PEAK = 256 * 4 * 16 * 2.4e9
+
+
+def survey_bytes(d, W, CS, K=2, PP=9, QF=8):
+    """ALGORITHMIC bytes of one proof per prover step, n = 2^d gates, N = 8n LDE rows.
+    Returns ({step: bytes}, total).  Steps are named after the kernel that does the bulk of them."""
+    n, N = 1 << d, 8 << d
+    zp, q = K * (1 + PP), K * QF
+    cols = W + zp + q                                 # columns committed per proof (wires, Z/PP, quotient chunks)
+    steps = {
+        "intt": (W + zp) * n * 16 + 2 * N * 16,       # values -> coefficients (read + write); quotient coset-iNTT
+        "lde": cols * (n * 8 + N * 8),                # coefficients in, 8x LDE values out
+        "leaf_hash": cols * N * 8 + 3 * 32 * N,       # LDE rows in, leaf digests out
+        "merkle": 3 * 32 * N,                         # digests in, inner nodes out
+        "zs": 2 * 80 * n * 8 + zp * n * 8,            # wires + sigmas in, Z/PP out
+        "quotient": (W + CS + zp) * N * 8 + 2 * N * 8,
+        "openings_fri_reduce": (CS + cols) * n * 8,   # one pass over every coefficient (openings + batch reduce)
+        "fri": int(0.01 * 8660 * N),
+    }
+    return steps, sum(steps.values())
+
+
+# kernel symbol (prefix) -> prover step of survey_bytes()
+KERNEL_STEP = [
+    ("ntt_pass_kernel<1,", "lde"), ("lde_", "lde"), ("ntt_pass_kernel<0,", "intt"), ("intt_", "intt"),
+    ("hash_lde", "leaf_hash"), ("merkle", "merkle"), ("zs_", "zs"), ("quotient", "quotient"), ("poseidon_gate", "quotient"),
+    ("eval_columns", "openings_fri_reduce"), ("reduce_columns", "openings_fri_reduce"),
+]
+
+
+def step_of(kernel):
+    k = kernel.replace(" ", "")
+    for pre, step in KERNEL_STEP:
+        if k.startswith(pre.replace(" ", "")):
+            return step
+    return None
+
+
+def newest(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
     (profiles/rNN*_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-    command, gfx950 read-side x2 correction).  None when no summary is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-    if not files:
+    command, gfx950 read-side x2 correction).  None when the summary does not hold the kernel."""
+    f = newest("r*_pmc_summary.json")
+    if not f:
         return None, None
     try:
-        with open(files[-1]) as f:
-            k = json.load(f)["kernels"].get(kernel)
-        return (k["hbm_bytes_per_launch"] if k else None), os.path.basename(files[-1])
+        with open(f) as fh:
+            k = json.load(fh)["kernels"].get(kernel)
+        return (k["hbm_bytes_per_launch"] if k else None), os.path.basename(f)
     except Exception:
         return None, None
 
 
-VALU_PEAK = 256 * 4 * 16 * 2.4e9  # lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes/cycle x 2.4 GHz (MI355X_MICROARCH.md)
-
-
-def issue_roofline(kernel, achieved_gbps):
-    """What actually bounds the integer kernels: VALU lane-instructions per HBM byte of
-    `kernel` from the committed rocprofv3 passes (SQ_INSTS_VALU x 64 lanes / (FETCH + WRITE bytes), same
-    command), times the live byte rate, against the chip's VALU issue peak.  None without a summary."""
-    import glob
-    sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_summary.json")))
-    pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-    if not sq or not pm:
+def issue_roofline(kernel, launches_per_sec):
+    """VALU issue side of the dominant kernel: lane-instructions per launch from the committed SQ pass
+    (SQ_INSTS_VALU x 64) x live launches/s of kernel time, against the measured issue ceiling."""
+    f = newest("r*_sq_summary.json")
+    if not f:
         return None
     try:
-        with open(sq[-1]) as f:
-            insts = json.load(f)["kernels"][kernel]["SQ_INSTS_VALU"] * 64.0
-        with open(pm[-1]) as f:
-            nbytes = json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
-        per_byte = insts / nbytes
-        rate = per_byte * achieved_gbps * 1e9
-        return {"bound": "valu-issue", "lane_instr_per_byte": per_byte, "achieved": rate, "peak": VALU_PEAK,
-                "unit": "lane-instr/s", "frac": rate / VALU_PEAK, "source": os.path.basename(sq[-1])}
+        with open(f) as fh:
+            insts = json.load(fh)["kernels"][kernel]["SQ_INSTS_VALU"] * 64.0
+        rate = insts * launches_per_sec
+        return {"bound": "valu-issue", "lane_instr_per_launch": insts, "achieved": rate, "peak": VALU_PEAK,
+                "unit": "lane-instr/s", "frac": rate / VALU_PEAK, "source": os.path.basename(f),
+                "peak_source": "profiles/r02_ubench.txt"}
     except Exception:
         return None
 
 
-def cpu_baseline(pkg, d_sample, d_target, mix):
-    """Oracle (CPU port of the same path) on a bounded sample: one proof at 2^d_sample gates,
-    scaled linearly to the target size (NTT log factor ignored -> favours the CPU)."""
+def cpu_baseline(pkg, d, mix, n_pi, single_thread_bits):
+    """The oracle (CPU port of the same path, oracle/) on the SAME circuit the GPU was timed on, all host
+    cores, one proof, no scaling; plus a one-thread leg on a bounded smaller sample (a full one-thread
+    proof at 2^20 rows takes minutes).  Test infrastructure, timed as a baseline -- never the target."""
+    import subprocess
     orc = entry.load_oracle()
     cores = orc.lib().orc_num_threads()
-    blob, wires = pkg.make_circuit(d_sample, mix, seed=1)
+    made = pkg.make_circuit(d, mix, seed=1, num_public_inputs=n_pi)
+    blob, wires = made[0], made[1]
+    pis = made[2] if n_pi else ()
     oc = orc.OracleCircuit(blob)          # circuit precompute is outside the timed call, as on the GPU
     t0 = time.perf_counter()
-    proof, tr = oc.prove(wires)
+    proof, tr = oc.prove(wires, public_inputs=pis)
     dt = time.perf_counter() - t0
-    scale = float(1 << (d_target - d_sample))
-    return {
-        "value": 1.0 / (dt * scale),
-        "unit": "proofs/sec",
-        "cores": int(cores),
-        "kind": "port",
-        "sample": f"1 proof of synth(d={d_sample},{mix}) = 2^{d_sample + 3} LDE rows in {dt:.2f} s on {cores} OpenMP threads, "
-                  f"scaled x{int(scale)} (linear in rows) to 2^{d_target + 3} LDE rows; oracle/ C restatement, not upstream plonky2",
-        "seconds_sample": dt,
+    oc.close()
+    try:
+        cpu = subprocess.run(["sh", "-c", "grep -m1 'model name' /proc/cpuinfo | cut -d: -f2"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        cpu = ""
+    out = {
+        "value": 1.0 / dt, "unit": "proofs/sec", "cores": int(cores), "kind": "port",
+        "sample": f"1 full proof of synth(d={d},{mix}) = 2^{d + 3} LDE rows (the benchmarked circuit, unscaled) in {dt:.2f} s on "
+                  f"{cores} OpenMP threads ({cpu}); oracle/ C restatement, not upstream plonky2 (no AVX2 field/Keccak kernels)",
+        "seconds": dt,
+        "phase_seconds": {"wires": tr.t_wires, "zs": tr.t_zs, "quotient": tr.t_quotient, "openings": tr.t_openings, "fri": tr.t_fri},
     }
+    if single_thread_bits:
+        ds = min(single_thread_bits, d)
+        code = ("import sys,time;sys.path.insert(0,%r);import __graft_entry__ as e;p=e.load_package();o=e.load_oracle();"
+                "m=p.make_circuit(%d,%r,seed=1);c=o.OracleCircuit(m[0]);t=time.perf_counter();c.prove(m[1]);print(time.perf_counter()-t)"
+                % (ROOT, ds, mix))
+        try:
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, OMP_NUM_THREADS="1"))
+            t1 = float(r.stdout.strip().splitlines()[-1])
+            out["single_thread"] = {"seconds_sample": t1, "sample": f"1 proof of synth(d={ds},{mix}) = 2^{ds + 3} LDE rows, OMP_NUM_THREADS=1",
+                                    "proofs_per_sec_scaled": 1.0 / (t1 * (1 << (d - ds))),
+                                    "scaling": f"x{1 << (d - ds)} (linear in rows; ignores the NTT log factor, which favours the CPU)"}
+        except Exception as e:  # the baseline is informative; never fail the bench for it
+            out["single_thread"] = {"error": str(e)[:200]}
+    return out
 
 
 def main():
@@ -101,9 +164,10 @@ def main():
                     help="public inputs of the synthetic circuit (> 0 adds PoseidonGate rows to the circuit and the "
                          "PoseidonGate to the gate set every LDE row evaluates); 0 = the BASELINE parity shape")
     ap.add_argument("--in-flight", type=int, default=1,
-                    help="independent proofs in flight per GPU (separate circuit handles / HIP streams, one host "
-                         "thread each): hides the latency-bound Merkle-tree tails and host round trips of one proof "
-                         "behind the kernels of another; 1 = strictly one proof at a time")
+                    help="independent proofs in flight per GPU IN THE TIMED REGION (separate circuit handles / HIP streams, "
+                         "one host thread each); 1 = strictly one proof at a time, so ms_per_step is a prove latency")
+    ap.add_argument("--pipelined", type=int, default=3,
+                    help="N = 1: after the timed region, also measure this many proofs in flight (0 = skip)")
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
                     help="N > 1: `replicas` = independent proofs per GPU (throughput, weak scaling, default); "
                          "`sharded` = ONE proof coset-sharded over the N GPUs (latency, strong scaling; RCCL "
@@ -112,7 +176,9 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the "
                          "multi-rank flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-bits", type=int, default=14)
+    ap.add_argument("--cpu-single-thread-bits", type=int, default=12,
+                    help="degree bits of the one-thread oracle sample (0 = skip the one-thread leg)")
+    ap.add_argument("--profile-steps", type=int, default=4)
     args = ap.parse_args()
 
     import torch
@@ -162,59 +228,96 @@ def main():
 
     import threading
 
-    def run(n_proofs, collect=None):
-        """n_proofs proofs over the S handles (thread i proves every S-th proof)."""
+    def run(handles, n_proofs, collect=None, w=None):
+        """n_proofs proofs over the handles (thread i proves every len(handles)-th proof)."""
+        w = wires_dev if w is None else w
+        k = len(handles)
+
         def work(i):
             last = None
-            for _ in range(i, n_proofs, S):
-                last = cds[i].prove(wires_dev, public_inputs=pis)
+            for _ in range(i, n_proofs, k):
+                last = handles[i].prove(w, public_inputs=pis)
                 if collect is not None:
                     collect.append(last.timings)
             results[i] = last
-        results = [None] * S
-        th = [threading.Thread(target=work, args=(i,)) for i in range(S)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+        results = [None] * k
+        if k == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(i,)) for i in range(k)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
         return next(r for r in results if r is not None)
 
-    proof = run(max(args.warmup, S))
-    for cd in cds:
-        cd.set("profile", 1)  # per-launch HIP events on each handle's stream, over the timed region
+    # ---- warm-up, then the timed region: K proofs, nothing but the production path ----
+    proof = run(cds, max(args.warmup, S))
     barrier()
     t0 = time.perf_counter()
     tms = []
-    proof = run(args.steps, tms)
+    proof = run(cds, args.steps, tms)
     barrier()
     dt = time.perf_counter() - t0
     dt = pkg.parallel.max_over_ranks(dt)
-    stats = {}
-    for cd in cds:
-        for k, v in cd.kernel_stats().items():
-            a = stats.setdefault(k, {"ms": 0.0, "bytes": 0.0, "launches": 0})
-            for f in a:
-                a[f] += v[f]
-        cd.set("profile", 0)
     phase = {}
     for t in tms:
         for k, v in t.items():
             if k.endswith("_ms"):
                 phase[k] = phase.get(k, 0.0) + v
-    # single-proof latency (nothing else in flight), measured after the timed region
-    cds[0].prove(wires_dev, public_inputs=pis)
-    torch.cuda.synchronize()
-    tl = time.perf_counter()
-    for _ in range(3):
-        cds[0].prove(wires_dev, public_inputs=pis)
-    latency_ms = (time.perf_counter() - tl) / 3 * 1e3
+
+    # ---- separate passes (not part of `value`) ----
     cd = cds[0]
+    # (a) per-launch HIP events on the library's launch stream -> roofline of the dominant kernel
+    cd.set("profile", 1)
+    P = max(1, args.profile_steps)
+    run([cd], P)
+    stats = cd.kernel_stats()
+    cd.set("profile", 0)
+    # (b) the same proofs with the witness in HOST memory: p2gpu_prove, H2D inside the call (N = 1 only: PCIe is shared)
+    host = None
+    if world == 1:
+        run([cd], 1, w=wires)
+        th = []
+        t1 = time.perf_counter()
+        run([cd], 3, th, w=wires)
+        host_ms = (time.perf_counter() - t1) / 3 * 1e3
+        host = {"entry_point": "p2gpu_prove (witness in host RAM -> proof bytes in host RAM)", "ms_per_proof": host_ms,
+                "proofs_per_sec": 1e3 / host_ms, "h2d_ms": sum(t["h2d_ms"] for t in th) / 3,
+                "witness_bytes": int(wires.nbytes), "note": "H2D runs in column chunks on a copy stream, overlapped with the "
+                "transforms / leaf hashing of the chunks already on the device; h2d_ms is the copy stream's span"}
+    # (c) several proofs in flight on one GPU (throughput mode of a proving service)
+    pipe = None
+    if world == 1 and not sharded and args.pipelined > 1 and S == 1 and d <= 19:
+        extra = [pkg.CircuitData(blob) for _ in range(args.pipelined - 1)]
+        hs = [cd] + extra
+        run(hs, 2 * len(hs))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        npipe = max(args.steps, 3 * len(hs))
+        run(hs, npipe)
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - t1
+        pipe = {"in_flight": len(hs), "proofs": npipe, "proofs_per_sec": npipe / dtp, "ms_per_proof": dtp / npipe * 1e3}
+        for h in extra:
+            h.close()
 
     if rank == 0:
         total_proofs = args.steps if sharded else world * args.steps
+        hdr = blob[:256].view(np.uint32)
+        W, CS = int(hdr[3]), int(hdr[5]) + int(hdr[4])
+        steps_b, total_b = survey_bytes(d, W, CS)
+        ms_step = dt / args.steps * 1e3
         name, st = max(stats.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = st["ms"] / st["launches"]
-        gbps = (st["bytes"] / st["launches"]) / (avg_ms * 1e-3) / 1e9
+        launches_per_proof = st["launches"] / P
+        step = step_of(name)
+        # SURVEY 8(d) bytes of the kernel's step, shared by every kernel symbol of that step in proportion to its time
+        step_ms = sum(v["ms"] for k, v in stats.items() if step_of(k) == step) or st["ms"]
+        alg_per_launch = (steps_b.get(step, 0.0) * (st["ms"] / step_ms)) / launches_per_proof if step else st["bytes"] / st["launches"]
+        impl_per_launch = st["bytes"] / st["launches"]
+        gbps_alg = alg_per_launch / (avg_ms * 1e-3) / 1e9
+        gbps_impl = impl_per_launch / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(name)
         out = {
             "metric": f"proofs/sec at 2^{d + 3} LDE rows (prove latency = ms_per_step)",
@@ -223,45 +326,55 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": f"synth(d={d},{mix}): {1 << d} gates -> 2^{d + 3} LDE rows, 234 wires / 80 routed, "
+                "workload": f"synth(d={d},{mix}): {1 << d} gates -> 2^{d + 3} LDE rows, {W} wires / 80 routed, "
                             f"KeccakGoldilocksConfig, rate 8, cap 2^4, 28 queries, 16 PoW bits (BASELINE configs[2] shape)",
                 "degree_bits": d, "lde_rows": 1 << (d + 3), "mix": mix, "public_inputs": args.public_inputs,
-                "parallelism": (f"one proof coset-sharded over {world} GPUs (8/{world} LDE cosets each; all-gather of caps, "
+                "parallelism": (f"one proof coset-sharded over {world} GPUs (8/{world} LDE cosets each; RCCL all-gather of caps, "
                                 f"quotient interpolants, query openings)" if sharded else
                                 f"replicas x{world} (independent proofs per GPU, no data-path collective), "
-                                f"{S} proofs in flight per GPU"),
+                                f"{S} proof(s) in flight per GPU"),
                 "proof_bytes": len(proof),
-                "witness": "resident in HBM (p2gpu_prove_dev); proof bytes returned to host",
+                "witness": "resident in HBM when the timed region starts (p2gpu_prove_dev); proof bytes returned to host",
             },
             "roofline": {
                 "kernel": name,
                 "bound": "hbm",
-                "achieved": gbps,
+                "achieved": gbps_alg,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
-                "frac": gbps / HBM_PEAK_GBPS,
+                "frac": gbps_alg / HBM_PEAK_GBPS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "avg_launch_ms": avg_ms,
-                "launches_per_proof": st["launches"] / args.steps,
-                "algorithmic_bytes_per_launch": st["bytes"] / st["launches"],
-                "issue": issue_roofline(name, gbps),
+                "launches_per_proof": launches_per_proof,
+                "algorithmic_bytes_per_launch": alg_per_launch,
+                "algorithmic_bytes_definition": f"SURVEY.md 8(d) bytes of prover step '{step}' ({steps_b.get(step, 0) / 1e9:.3f} GB per proof) "
+                                                f"/ launches of that step per proof",
+                "implementation_bytes_per_launch": impl_per_launch,
+                "frac_traffic": gbps_impl / HBM_PEAK_GBPS,
+                "whole_proof": {"algorithmic_bytes": total_b, "achieved": total_b / (ms_step * 1e-3) / 1e9, "unit": "GB/s",
+                                "frac": total_b / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                "note": "B(N) / t_prove of SURVEY.md 8(d); the prover is VALU-issue-bound, see `issue`"},
+                "issue": issue_roofline(name, 1e3 / avg_ms),
             },
-            "latency_ms_single_proof": latency_ms,
+            "latency_ms_single_proof": ms_step if S == 1 else None,
             "in_flight_per_gpu": S,
+            "host_witness": host,
+            "pipelined": pipe,
             "phase_ms": {k: v / args.steps for k, v in sorted(phase.items())},
-            "kernel_ms_per_proof": {k: round(v["ms"] / args.steps, 4) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])},
+            "kernel_ms_per_proof": {k: round(v["ms"] / P, 4) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])},
+            "kernel_profile": f"{P} extra proofs after the timed region with per-launch HIP events (profile = 1)",
             "device": pkg.device_info()["name"],
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, min(args.cpu_sample_bits, d), d, mix)
+            out["cpu_baseline"] = cpu_baseline(pkg, d, mix, args.public_inputs, args.cpu_single_thread_bits)
         print(json.dumps(out), flush=True)
     for c_ in cds:
         c_.close()

@@ -83,6 +83,28 @@ struct DBuf {
   }
 };
 
+// bump arena in pinned host memory, reset at the start of every proof
+struct PinnedArena {
+  uint8_t *base = nullptr;
+  size_t cap = 0, used = 0;
+  hipError_t alloc(size_t bytes) {
+    cap = bytes;
+    used = 0;
+    return hipHostMalloc((void **)&base, bytes, hipHostMallocDefault);
+  }
+  void release() {
+    if (base) (void)hipHostFree(base);
+    base = nullptr;
+  }
+  void reset() { used = 0; }
+  template <class T> T *take(size_t n) {
+    const size_t off = (used + 63) & ~(size_t)63, bytes = n * sizeof(T);
+    if (!base || off + bytes > cap) return nullptr;
+    used = off + bytes;
+    return (T *)(base + off);
+  }
+};
+
 // one committed polynomial batch (plonky2 PolynomialBatch), GPU layout
 struct Batch {
   uint32_t cols = 0, d = 0;
@@ -145,6 +167,7 @@ struct CircuitState {
   std::vector<DBuf<gl_t>> fri_coef, fri_vals;
   std::vector<Batch> fri_trees;  // only dig/level_off/cap used
   DBuf<unsigned long long> pow_result;
+  PinnedArena pin;
   DBuf<uint64_t> gather_ptrs;
   DBuf<gl_t> gather_out;
   size_t gather_cap = 0;

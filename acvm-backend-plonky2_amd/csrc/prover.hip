@@ -52,6 +52,34 @@ bool trace_on() {
     }                                                                                       \
   } while (0)
 
+// P2GPU_HOSTPROF=1: host-side timestamps at the transcript sync points of one proof (no extra
+// synchronisation), printed at the end of prove: where the host sits between GPU phases
+bool hostprof_on() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("P2GPU_HOSTPROF");
+    v = (e && *e && *e != '0') ? 1 : 0;
+  }
+  return v == 1;
+}
+struct HostProf {
+  std::vector<std::pair<const char *, double>> ev;
+  void mark(const char *label);
+  void dump();
+};
+double now_ms();
+void HostProf::mark(const char *label) {
+  if (hostprof_on()) ev.push_back({label, now_ms()});
+}
+void HostProf::dump() {
+  if (!hostprof_on() || ev.empty()) return;
+  fprintf(stderr, "[p2gpu hostprof]");
+  for (size_t i = 1; i < ev.size(); i++) fprintf(stderr, " %s %+.1fus |", ev[i].first, (ev[i].second - ev[i - 1].second) * 1e3);
+  fprintf(stderr, " total %.3f ms\n", ev.back().second - ev.front().second);
+  ev.clear();
+}
+thread_local HostProf g_hp;
+
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -128,6 +156,11 @@ int shard_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size
   return 0;
 }
 
+int pin_exhausted() {
+  set_err("internal: pinned staging arena exhausted");
+  return P2GPU_E_DEVICE;
+}
+
 // level offsets of a tree over [cosets][m0] leaf digests reduced to cap_per nodes per coset
 void tree_layout(Batch &b, uint32_t cosets, size_t m0, size_t cap_per) {
   b.level_off.clear();
@@ -151,12 +184,26 @@ int tree_alloc(Batch &b, uint32_t C, size_t m0, size_t cap_per) {
   return 0;
 }
 
+// Levels with more nodes per coset than this are one grid-wide launch each; below it, one block per
+// coset walks the remaining levels in a single launch (merkle.hip merkle_tail_kernel).  A tail level
+// costs one dependent Keccak-f (~9 us) however few nodes it has, but only as long as every lane has at
+// most one node: with 1024 lanes per coset that is 2048 nodes per coset (measured on MI355X, d = 17:
+// switching at 4096 nodes: 9.09 ms per proof, 2048: 8.93, 1024: 8.75, 512: 8.86; P2GPU_TAIL_NODES overrides).
+size_t tail_nodes() {
+  static size_t v = 0;
+  if (!v) {
+    const char *e = getenv("P2GPU_TAIL_NODES");
+    v = e && atoi(e) >= 2 ? (size_t)atoi(e) : 1024;
+  }
+  return v;
+}
+
 int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
   const uint32_t C = c->C, CL = b.ncl;
   size_t m = m0;
   const size_t cap_target = ((size_t)1 << c->cap_h) >> c->rate_bits;
   for (size_t l = 1; l < b.level_off.size(); l++) {
-    if (m <= 4096) {  // the rest of the tree in one launch
+    if (m <= tail_nodes()) {  // the rest of the tree in one launch
       merkle_tail(c->stream, b.dig.p + b.level_off[l - 1], CL, (uint32_t)m, (uint32_t)cap_target);
       m = cap_target;
       break;
@@ -165,11 +212,14 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
     m >>= 1;
   }
   const size_t cap_per = m;
-  std::vector<dig_t> raw(C * cap_per);  // [global coset][cap_per]
+  dig_t *raw = c->pin.take<dig_t>(C * cap_per);  // [global coset][cap_per]; pinned: the D2H below is a true async copy
+  if (!raw) return pin_exhausted();
   if (CL == C) {
-    HIP_TRY(hipMemcpyAsync(raw.data(), b.dig.p + b.level_off.back(), raw.size() * sizeof(dig_t), hipMemcpyDeviceToHost,
+    HIP_TRY(hipMemcpyAsync(raw, b.dig.p + b.level_off.back(), C * cap_per * sizeof(dig_t), hipMemcpyDeviceToHost,
                            c->stream));
+    g_hp.mark("enq(cap)");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    g_hp.mark("WAIT(cap)");
   } else {
     // coset r owns whole cap subtrees: exchange the CL * cap_per local roots (the path's only
     // commitment-time collective: 16 x 25 B in total)
@@ -289,7 +339,9 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   gl_t pih[4];  // public_inputs_hash = InnerHasher(Poseidon).hash_no_pad(public_inputs); [] -> 0^4
   poseidon_hash_no_pad_host(pis, n_pi, pih, c->poseidon_rc);
 
+  c->pin.reset();
   // ---- 1. wires commitment ----
+  g_hp.mark("start");
   TRACE(c, "enter");
   if (int rc = batch_commit_from_values(c, c->wires, wires_dev)) return rc;
   TRACE(c, "wires commit");
@@ -328,7 +380,9 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   // ---- 3. quotient ----
   {
     const uint32_t nterms = c->nterms;
-    std::vector<gl_t> ap((size_t)2 * nterms, 0);
+    gl_t *ap = c->pin.take<gl_t>((size_t)2 * nterms);
+    if (!ap) return pin_exhausted();
+    memset(ap, 0, 16 * (size_t)nterms);
     for (uint32_t k = 0; k < K; k++) {
       gl_t a = 1;
       for (uint32_t t = 0; t < nterms; t++) {
@@ -336,7 +390,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
         a = gl_mul(a, alphas[k]);
       }
     }
-    HIP_TRY(hipMemcpyAsync(c->apow.p, ap.data(), ap.size() * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->apow.p, ap, 16 * (size_t)nterms, hipMemcpyHostToDevice, st));
     QuotArgs q;
     memset(&q, 0, sizeof q);
     q.cs_lde = c->cs.lde.p;
@@ -416,9 +470,13 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     {
       eval_columns(st, c->zp.coeffs.p, K, d, c->pw.p + 2 * n, parts, c->partial.p + base * parts * 2);
     }
-    std::vector<gl_t> part((size_t)(nall + K) * parts * 2);
-    HIP_TRY(hipMemcpyAsync(part.data(), c->partial.p, part.size() * 8, hipMemcpyDeviceToHost, st));
+    const size_t npart = (size_t)(nall + K) * parts * 2;
+    gl_t *part = c->pin.take<gl_t>(npart);
+    if (!part) return pin_exhausted();
+    HIP_TRY(hipMemcpyAsync(part, c->partial.p, npart * 8, hipMemcpyDeviceToHost, st));
+    g_hp.mark("enq(openings)");
     HIP_TRY(hipStreamSynchronize(st));
+    g_hp.mark("WAIT(openings)");
     for (size_t j = 0; j < nall + K; j++) {
       gl_t a0 = 0, a1 = 0;
       for (uint32_t p = 0; p < parts; p++) {
@@ -429,18 +487,16 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     }
   }
   TRACE(c, "openings");
-  if (c->self_check && !plonk_identity_holds(c, op, betas, gammas, alphas, zeta, pih)) {
-    set_err("witness does not satisfy the circuit: the plonk identity fails at zeta (vanishing != Z_H * quotient)");
-    return P2GPU_E_UNSATISFIED;
-  }
   for (size_t j = 0; j < nall + K; j++) ch.observe_ext(op[j]);
+  g_hp.mark("observe(openings)");
   t0 = now_ms();
   T.openings_ms = t0 - t1;
 
   // ---- 5. FRI ----
   const ext_t alpha = ch.get_ext();
   {
-    std::vector<gl_t> apw((size_t)2 * nall);
+    gl_t *apw = c->pin.take<gl_t>((size_t)2 * nall);
+    if (!apw) return pin_exhausted();
     ext_t a = ext_from(1);
     ext_t f0z = ext_from(0), f1z = ext_from(0);
     for (uint32_t j = 0; j < nall; j++) {
@@ -450,7 +506,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
       if (j < K) f1z = ext_add(f1z, ext_mul(a, op[nall + j]));
       a = ext_mul(a, alpha);
     }
-    HIP_TRY(hipMemcpyAsync(c->ext_apow.p, apw.data(), apw.size() * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->ext_apow.p, apw, 16 * (size_t)nall, hipMemcpyHostToDevice, st));
     gl_t *F0 = c->f01.p, *F1 = c->f01.p + 2 * n;
     uint32_t j0 = 0;
     for (int o = 0; o < 4; o++) {
@@ -474,6 +530,14 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     }
   }
   TRACE(c, "fri final poly lde");
+  // the self-check needs only the openings and the challenges: it runs on the host while the GPU is
+  // busy with the batch reduction and the FRI LDE enqueued above, off the critical path
+  if (c->self_check && !plonk_identity_holds(c, op, betas, gammas, alphas, zeta, pih)) {
+    (void)hipStreamSynchronize(st);
+    set_err("witness does not satisfy the circuit: the plonk identity fails at zeta (vanishing != Z_H * quotient)");
+    return P2GPU_E_UNSATISFIED;
+  }
+  g_hp.mark("selfcheck");
   std::vector<ext_t> fri_betas;
   uint32_t ds = d;
   gl_t shift = GL_GEN;
@@ -498,9 +562,12 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   const size_t n_final = (size_t)1 << ds;
   std::vector<ext_t> final_poly(n_final);
   {
-    std::vector<gl_t> raw(2 * n_final);
-    HIP_TRY(hipMemcpyAsync(raw.data(), c->fri_coef[c->n_steps].p, raw.size() * 8, hipMemcpyDeviceToHost, st));
+    gl_t *raw = c->pin.take<gl_t>(2 * n_final);
+    if (!raw) return pin_exhausted();
+    HIP_TRY(hipMemcpyAsync(raw, c->fri_coef[c->n_steps].p, 16 * n_final, hipMemcpyDeviceToHost, st));
+    g_hp.mark("enq(final_poly)");
     HIP_TRY(hipStreamSynchronize(st));
+    g_hp.mark("WAIT(final_poly)");
     for (size_t j = 0; j < n_final; j++) {
       size_t p = brev((uint32_t)j, ds);
       final_poly[j] = ext_make(raw[p], raw[n_final + p]);
@@ -518,14 +585,18 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     // expected minimum witness ~2^pow_bits: start with 2^(pow_bits+1) candidates, then double
     uint64_t batch = 1ull << (c->pow_bits + 1 < 20 ? c->pow_bits + 1 : 20);
     for (uint64_t base = 0;; base += batch, batch = batch < (1ull << 22) ? batch * 2 : batch) {
-      unsigned long long init = ~0ull;
-      HIP_TRY(hipMemcpyAsync(c->pow_result.p, &init, 8, hipMemcpyHostToDevice, st));
+      unsigned long long *pw = c->pin.take<unsigned long long>(2);
+      if (!pw) return pin_exhausted();
+      pw[0] = ~0ull;
+      HIP_TRY(hipMemcpyAsync(c->pow_result.p, &pw[0], 8, hipMemcpyHostToDevice, st));
       {
         pow_search(st, inter, (uint32_t)ch.n_in, c->pow_bits, base, batch, c->pow_result.p);
       }
-      unsigned long long res;
-      HIP_TRY(hipMemcpyAsync(&res, c->pow_result.p, 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(&pw[1], c->pow_result.p, 8, hipMemcpyDeviceToHost, st));
+      g_hp.mark("enq(pow)");
       HIP_TRY(hipStreamSynchronize(st));
+      g_hp.mark("WAIT(pow)");
+      const unsigned long long res = pw[1];
       if (res != ~0ull) {
         pow_witness = res;
         break;
@@ -609,14 +680,19 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     set_err("internal: gather buffer too small");
     return P2GPU_E_DEVICE;
   }
-  std::vector<gl_t> gathered(ptrs.size());
-  HIP_TRY(hipMemcpyAsync(c->gather_ptrs.p, ptrs.data(), ptrs.size() * 8, hipMemcpyHostToDevice, st));
+  gl_t *gathered = c->pin.take<gl_t>(ptrs.size());
+  uint64_t *pptrs = c->pin.take<uint64_t>(ptrs.size());
+  if (!gathered || !pptrs) return pin_exhausted();
+  memcpy(pptrs, ptrs.data(), ptrs.size() * 8);
+  HIP_TRY(hipMemcpyAsync(c->gather_ptrs.p, pptrs, ptrs.size() * 8, hipMemcpyHostToDevice, st));
   {
     gather_u64(st, c->gather_ptrs.p, (uint32_t)ptrs.size(), c->gather_out.p);
   }
   if (world == 1) {
-    HIP_TRY(hipMemcpyAsync(gathered.data(), c->gather_out.p, ptrs.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(gathered, c->gather_out.p, ptrs.size() * 8, hipMemcpyDeviceToHost, st));
+    g_hp.mark("enq(gather)");
     HIP_TRY(hipStreamSynchronize(st));
+    g_hp.mark("WAIT(gather)");
   } else {
     // each rank gathered the queries that fall into its cosets: exchange and pick every query
     // from its owner
@@ -684,6 +760,8 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   }
   memcpy(proof_out, out.v.data(), out.v.size());
   *proof_len = out.v.size();
+  g_hp.mark("serialise");
+  g_hp.dump();
   return P2GPU_OK;
 }
 
@@ -699,6 +777,7 @@ void circuit_release(p2gpu_circuit *c) {
   for (auto &b : c->fri_vals) b.release();
   for (auto &b : c->fri_trees) b.release();
   c->hash_state.release();
+  c->pin.release();
   c->pow_result.release(); c->gather_ptrs.release(); c->gather_out.release(); c->xchg_recv.release();
   ntt_plan_destroy(c->plan_inv);
   ntt_plan_destroy(c->plan_fwd);
@@ -990,6 +1069,14 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   CK(c->gather_ptrs.alloc(c->gather_cap), "alloc gather");
   CK(c->gather_out.alloc(c->gather_cap), "alloc gather");
   CK(c->pow_result.alloc(1), "alloc pow");
+  // pinned host arena for every small transcript transfer of a proof (caps, opening partials, challenge
+  // powers, final polynomial, PoW result, query gather): with pageable memory each of those
+  // hipMemcpyAsync calls blocks in a staging copy and the following stream sync costs another ~10 us
+  {
+    size_t n_final = n;
+    for (uint32_t s = 0; s < c->n_steps; s++) n_final >>= c->arity[s];
+    CK(c->pin.alloc(16 * c->gather_cap + 32 * n_final + 16 * (size_t)(nall + K) * 16 + ((size_t)1 << 18)), "alloc pinned staging");
+  }
 
   mark("batch + work buffer allocation");
   // ---- constants_sigmas commitment (the prover-side part of `build()`) ----
@@ -1280,7 +1367,7 @@ int p2gpu_commit_values(const uint64_t *vals, size_t ncols, unsigned d, unsigned
   do {
     if (hipStreamCreate(&c->stream) != hipSuccess || c->tw_fwd.alloc(half) != hipSuccess ||
         c->tw_inv.alloc(half) != hipSuccess || c->scale.alloc((size_t)c->C * n) != hipSuccess ||
-        c->wires_vals.alloc(ncols * n) != hipSuccess) {
+        c->wires_vals.alloc(ncols * n) != hipSuccess || c->pin.alloc((size_t)1 << 16) != hipSuccess) {
       set_err("hipMalloc failed");
       rc = P2GPU_E_DEVICE;
       break;

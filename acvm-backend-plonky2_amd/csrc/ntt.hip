@@ -23,6 +23,7 @@
 // layers instead of 32.  This kernel is integer-ALU bound on gfx950 (a 64x64
 // modmul is ~29 VALU); the HBM traffic equals the algorithmic bytes.  No MFMA.
 #include "internal.hpp"
+#include "glphi.hpp"
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -105,6 +106,11 @@ __device__ __forceinline__ void dft_regs(gl_t (&v)[1 << LOGR]) {
 __device__ __forceinline__ uint32_t pidx(uint32_t e) { return e + (e >> 4); }
 
 constexpr int MAX_ROUNDS = 4;
+#ifndef NTT_PHI
+#define NTT_PHI 0  // 1: butterfly networks on signed a + b*2^32 components (glphi.hpp).  Measured on MI355X (d = 17):
+                   // 21 % fewer VALU per radix-16 round, but 150-200 VGPRs instead of 98 (2-3 waves per SIMD
+                   // instead of 4): LDE 3.42 ms vs 3.22 ms -- not faster, so it stays an opt-in variant
+#endif
 #ifndef NTT_TILE_BITS
 #define NTT_TILE_BITS 12
 #endif
@@ -118,7 +124,8 @@ struct PassArgs {
   uint32_t s;         // log2 global stride of the pass's lowest layer
   uint32_t a;         // layers in this pass
   uint32_t tb;        // log2 contiguous run; tile = 2^(a+tb)
-  uint32_t cols;
+  uint32_t cols;        // column stride between cosets in src / dst
+  uint32_t tiles, cols_grid, cosets;  // launch shape (1-D grid, decoded XCD-aware in the kernel)
   uint32_t src_single;  // 1: src has no coset dimension
   uint32_t coset_first, coset_stride;  // global coset of grid.z = first + z * stride (indexes `scale`)
   uint32_t nrounds;
@@ -131,8 +138,86 @@ __device__ __forceinline__ uint32_t gidx(uint32_t e, uint32_t hi_base, uint32_t 
 }
 
 // one round: layers on tile bits [beta0, beta0 + LOGR); the group twiddle of position j is
-// theta^(bitrev(j)), theta = w_{2^(s0+LOGR)}^(lo), read from the packed table T[(e-1)*M + lo]
-template <int DIT, bool INV, int LOGR>
+// theta^(bitrev(j)), theta = w_{2^(s0+LOGR)}^(lo), read from the packed table T[(e-1)*M + lo].
+// MUL = (s0 > 0): the round has general twiddles (the first round of a transform has none).
+#if NTT_PHI
+// The butterfly network runs on a + b*2^32 with signed 64-bit components (glphi.hpp): plain 64-bit
+// adds, shifts for the power-of-two twiddles, compile-time placed renormalisations.  The general
+// twiddle products enter that form straight from their 128-bit value; what goes back to LDS is a
+// u64 congruent to the result (not necessarily < p) -- the next round's product and the pass's
+// final store (gl_canon) take any u64.
+template <int DIT, bool INV, int LOGR, bool MUL>
+__device__ __forceinline__ void round_regs(gl_t *lds, const PassArgs &A, uint32_t TB, uint32_t beta0, uint32_t lo0,
+                                           const gl_t *tw) {
+  constexpr int R = 1 << LOGR;
+  const uint32_t ngroups = 1u << (TB - LOGR);
+  const uint32_t s0 = beta0 - A.tb + A.s;  // log2 M
+  const uint32_t M = 1u << s0;
+  typedef PhiNet<LOGR, DIT, INV, MUL && DIT ? phi_bound_mul().ma : phi_bound_from().ma,
+                 MUL && DIT ? phi_bound_mul().mb : phi_bound_from().mb> Net;
+  for (uint32_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
+    const uint32_t low = g & ((1u << beta0) - 1), high = g >> beta0;
+    const uint32_t base = (high << (beta0 + LOGR)) | low;
+    // global index of `base` modulo M
+    const uint32_t lo = (((base & ((1u << beta0) - 1)) >> A.tb) << A.s) + lo0 + (base & ((1u << A.tb) - 1));
+    phi_t w[R];
+    if constexpr (DIT && LOGR == 4) {
+      // 16 registers of two 64-bit components are 64 VGPRs; with all 16 words and 15 twiddles loaded up
+      // front on top of that the kernel loses half its occupancy.  Layers 0-2 of a DIT network never
+      // cross the two halves of the register array: finish the lower half, then load and finish the
+      // upper half, then the top layer pair by pair straight into LDS.
+      static_for<0, 2>([&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        gl_t x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = lds[pidx(base | ((uint32_t)(j + 8 * h) << beta0))];
+        static_for<0, 8>([&](auto jc) {
+          constexpr int j = decltype(jc)::value + 8 * h;
+          if constexpr (MUL && j > 0) w[j] = phi_mul_u64(x[j - 8 * h], tw[(size_t)(brev_c(j, LOGR) - 1) * M + lo]);
+          else w[j] = phi_from(x[j - 8 * h]);
+        });
+        Net::template run_part<0, 3, h>(w);
+        asm volatile("" ::: "memory");  // the other half's loads stay on their side of this point
+      });
+      static_for<0, 8>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        Net::template dit_top<j>(w);
+        lds[pidx(base | ((uint32_t)j << beta0))] = phi_to_u64(w[j]);
+        lds[pidx(base | ((uint32_t)(j + 8) << beta0))] = phi_to_u64(w[j + 8]);
+      });
+    } else {
+      gl_t v[R];
+#pragma unroll
+      for (int j = 0; j < R; j++) v[j] = lds[pidx(base | ((uint32_t)j << beta0))];
+      if constexpr (DIT) {
+        static_for<0, R>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if constexpr (MUL && j > 0) w[j] = phi_mul_u64(v[j], tw[(size_t)(brev_c(j, LOGR) - 1) * M + lo]);
+          else w[j] = phi_from(v[j]);
+        });
+        Net::run(w);
+#pragma unroll
+        for (int j = 0; j < R; j++) v[j] = phi_to_u64(w[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < R; j++) w[j] = phi_from(v[j]);
+        Net::run(w);
+#pragma unroll
+        for (int j = 0; j < R; j++) v[j] = phi_to_u64(w[j]);
+        if constexpr (MUL) {
+          static_for<1, R>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            v[j] = gl_mul(v[j], tw[(size_t)(brev_c(j, LOGR) - 1) * M + lo]);
+          });
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < R; j++) lds[pidx(base | ((uint32_t)j << beta0))] = v[j];
+    }
+  }
+}
+#else
+template <int DIT, bool INV, int LOGR, bool MUL>
 __device__ __forceinline__ void round_regs(gl_t *lds, const PassArgs &A, uint32_t TB, uint32_t beta0, uint32_t lo0,
                                            const gl_t *tw) {
   constexpr int R = 1 << LOGR;
@@ -142,56 +227,67 @@ __device__ __forceinline__ void round_regs(gl_t *lds, const PassArgs &A, uint32_
   for (uint32_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
     const uint32_t low = g & ((1u << beta0) - 1), high = g >> beta0;
     const uint32_t base = (high << (beta0 + LOGR)) | low;
-    // global index of `base` modulo M
     const uint32_t lo = (((base & ((1u << beta0) - 1)) >> A.tb) << A.s) + lo0 + (base & ((1u << A.tb) - 1));
     gl_t v[R];
 #pragma unroll
     for (int j = 0; j < R; j++) v[j] = lds[pidx(base | ((uint32_t)j << beta0))];
-    if (DIT) {
-      if (s0 > 0) {
-        static_for<1, R>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          constexpr int e = brev_c(j, LOGR);
-          v[j] = gl_mul(v[j], tw[(size_t)(e - 1) * M + lo]);
-        });
-      }
-      dft_regs<LOGR, 1, INV>(v);
-    } else {
-      dft_regs<LOGR, 0, INV>(v);
-      if (s0 > 0) {
-        static_for<1, R>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          constexpr int e = brev_c(j, LOGR);
-          v[j] = gl_mul(v[j], tw[(size_t)(e - 1) * M + lo]);
-        });
-      }
+    if constexpr (DIT && MUL) {
+      static_for<1, R>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        v[j] = gl_mul(v[j], tw[(size_t)(brev_c(j, LOGR) - 1) * M + lo]);
+      });
+    }
+    dft_regs<LOGR, DIT, INV>(v);
+    if constexpr (!DIT && MUL) {
+      static_for<1, R>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        v[j] = gl_mul(v[j], tw[(size_t)(brev_c(j, LOGR) - 1) * M + lo]);
+      });
     }
 #pragma unroll
     for (int j = 0; j < R; j++) lds[pidx(base | ((uint32_t)j << beta0))] = v[j];
   }
 }
+#endif
 
 template <int DIT, bool INV>
 __device__ __forceinline__ void do_round(gl_t *lds, const PassArgs &A, uint32_t TB, uint32_t beta0, uint32_t logr,
                                          uint32_t lo0, const gl_t *tw) {
+  const bool mul = beta0 - A.tb + A.s > 0;
+#define P2_ROUND(L)                                                        \
+  do {                                                                     \
+    if (mul) round_regs<DIT, INV, L, true>(lds, A, TB, beta0, lo0, tw);    \
+    else round_regs<DIT, INV, L, false>(lds, A, TB, beta0, lo0, tw);       \
+  } while (0)
   switch (logr) {
-  case 4: round_regs<DIT, INV, 4>(lds, A, TB, beta0, lo0, tw); break;
-  case 3: round_regs<DIT, INV, 3>(lds, A, TB, beta0, lo0, tw); break;
-  case 2: round_regs<DIT, INV, 2>(lds, A, TB, beta0, lo0, tw); break;
-  default: round_regs<DIT, INV, 1>(lds, A, TB, beta0, lo0, tw); break;
+  case 4: P2_ROUND(4); break;
+  case 3: P2_ROUND(3); break;
+  case 2: P2_ROUND(2); break;
+  default: P2_ROUND(1); break;
   }
+#undef P2_ROUND
 }
 
 // grid: x = tile index within a column, y = column, z = coset.
 // TBC = 12: the full 2^12-element tile with 256 lanes -- the global loads/stores of a lane are 16
 // independent accesses issued back to back (compile-time trip count) so their latencies overlap;
 // TBC = 0: any smaller tile (small transforms), runtime loops.
+#ifndef NTT_MIN_WAVES
+#define NTT_MIN_WAVES 1
+#endif
 template <int DIT, bool INV, int TBC>
-__global__ __launch_bounds__(256) void ntt_pass_kernel(PassArgs A) {
+__global__ __launch_bounds__(256, NTT_MIN_WAVES) void ntt_pass_kernel(PassArgs A) {
   extern __shared__ gl_t lds[];
   const uint32_t TB = TBC ? TBC : A.a + A.tb;
-  const uint32_t tile = blockIdx.x;
-  const uint32_t col = blockIdx.y, coset = blockIdx.z;
+  // XCD-aware block -> (tile, column, coset): the hardware deals consecutive block ids round-robin over
+  // the 8 XCDs, each with its own L2.  The 2^rate_bits coset transforms of one (tile, column) read the
+  // SAME coefficients (and neighbouring rows of the scale table): they get consecutive slots of ONE XCD,
+  // so the tile comes from HBM once and from that XCD's L2 afterwards.
+  const uint32_t units = A.tiles * A.cols_grid;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t coset = slot % A.cosets, unit = (slot / A.cosets) * 8u + xcd;
+  if (unit >= units) return;
+  const uint32_t tile = unit % A.tiles, col = unit / A.tiles;
   const size_t n = (size_t)1 << A.d;
   const uint32_t runs = 1u << (A.s - A.tb);  // lo-runs per hi block
   const uint32_t hi = tile / runs, lo0 = (tile % runs) << A.tb;
@@ -251,13 +347,16 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(PassArgs A) {
     if (post) {
 #pragma unroll
       for (int i = 0; i < PER; i++) x[i] = gl_mul(x[i], A.post);
+    } else {
+#pragma unroll
+      for (int i = 0; i < PER; i++) x[i] = gl_canon(x[i]);  // LDS holds congruent, not canonical, words
     }
 #pragma unroll
     for (int i = 0; i < PER; i++) dst[gidx(threadIdx.x + i * NT, hi_base, lo0, A.s, A.tb)] = x[i];
   } else {
     for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
       gl_t x = lds[pidx(e)];
-      if (post) x = gl_mul(x, A.post);
+      x = post ? gl_mul(x, A.post) : gl_canon(x);
       dst[gidx(e, hi_base, lo0, A.s, A.tb)] = x;
     }
   }
@@ -387,7 +486,8 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     for (int k = 0; k < MAX_ROUNDS; k++) { A.r[k] = ps.r[k]; A.tw_off[k] = ps.tw_off[k]; }
     const uint32_t TB = A.a + A.tb;
     const uint32_t tiles = 1u << (d - TB);
-    dim3 grid(tiles, cols, cosets);
+    A.tiles = tiles; A.cols_grid = cols; A.cosets = cosets;
+    dim3 grid((((tiles * cols + 7u) / 8u) * 8u) * cosets);
     const uint32_t threads = TB >= 8 ? 256 : 64;
     const double bytes = 16.0 * ((double)cols * cosets * ((size_t)1 << d));
     // same spelling as rocprofv3's demangled kernel names, so the bench line and profiles/ agree

@@ -53,7 +53,8 @@ class _DevBytes:
 
 
 def lib_path():
-    return os.path.join(_HERE, "libp2gpu.so")
+    # P2GPU_LIBRARY: an alternative build of the same library (A/B measurements of kernel variants only)
+    return os.environ.get("P2GPU_LIBRARY") or os.path.join(_HERE, "libp2gpu.so")
 
 
 def load_library():

@@ -110,7 +110,7 @@ int main(int argc, char **argv) {
     if (it % 5 == 0) { v.a = (rnd() & 1) ? INT64_MAX : INT64_MIN; }
     if (it % 11 == 0) { v.b = ((rnd() & 1) ? 1 : -1) * (int64_t)(PHI_MAX); }
     // reference through 128-bit integers
-    __int128 V = (__int128)v.a + (((__int128)v.b) << 32);
+    __int128 V = (__int128)v.a + (__int128)v.b * ((__int128)1 << 32);
     __int128 P = (__int128)GL_P;
     __int128 m = V % P;
     if (m < 0) m += P;

@@ -173,8 +173,10 @@ struct CircuitState {
   size_t gather_cap = 0;
   // coset sharding across ranks (one process per GPU); world = 1: everything local
   int shard_rank = 0, shard_world = 1;
-  p2gpu_allgather_fn shard_fn = nullptr;
+  p2gpu_allgather_fn shard_fn = nullptr;  // host callback transport (tests over gloo)
   void *shard_ctx = nullptr;
+  void *rccl_comm = nullptr;              // ncclComm_t: RCCL transport, collectives on `stream`
+  int shard_exercise = 0;                 // run the exchange steps even with world = 1 (plumbing test)
   DBuf<gl_t> xchg_recv;
   // knobs
   uint64_t pow_hint = UINT64_MAX;
@@ -203,6 +205,7 @@ struct p2gpu_circuit : p2::CircuitState {};
 
 namespace p2 {
 extern void (*g_circuit_release)(p2gpu_circuit *);  // hostcore.hip; set by prover.hip
+void shard_assemble_cap(int world, unsigned rate_bits, size_t cap_per, const dig_t *gathered, std::vector<dig_t> &cap);
 // blob header + gate table + (optional) cap + k_is -> the host-side fields of the handle; leaves
 // *off at the constants table.  Used by p2gpu_circuit_create and p2gpu_verifier_create.
 int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off, const uint8_t **cap_in);

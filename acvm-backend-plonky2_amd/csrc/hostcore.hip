@@ -27,6 +27,21 @@ void set_err(const char *fmt, ...) {
 }
 std::string last_error_copy() { return g_err; }
 void last_error_restore(const std::string &s) { g_err = s; }
+// Merkle cap in plonky2 order from the all-gather of every rank's local subtree roots:
+// gathered = [world][C / world local cosets][cap_per], rank q's local coset z being the global coset
+// r = q + z * world.  plonky2's leaf index bitrev(8k + r) has bitrev(r) as its top bits, so coset r
+// owns the cap entries bitrev(r) * cap_per + bitrev(k); world = 1 is the unsharded case.
+void shard_assemble_cap(int world, unsigned rate_bits, size_t cap_per, const dig_t *gathered, std::vector<dig_t> &cap) {
+  const uint32_t C = 1u << rate_bits, CL = C / (uint32_t)world;
+  unsigned lgp = 0;
+  while (((size_t)1 << lgp) < cap_per) lgp++;
+  cap.assign((size_t)C * cap_per, dig_t{});
+  for (int q = 0; q < world; q++)
+    for (uint32_t z = 0; z < CL; z++)
+      for (size_t k = 0; k < cap_per; k++)
+        cap[(size_t)bitrev32((uint32_t)q + z * (uint32_t)world, rate_bits) * cap_per + bitrev32((uint32_t)k, lgp)] =
+            gathered[((size_t)q * CL + z) * cap_per + k];
+}
 // set by prover.hip (the TU that owns device memory): releases a prover handle's device state
 void (*g_circuit_release)(p2gpu_circuit *) = nullptr;
 }  // namespace p2
@@ -199,6 +214,17 @@ int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off
 }  // namespace p2
 
 extern "C" {
+
+int p2gpu_shard_assemble_cap(int world, unsigned rate_bits, unsigned cap_h, const uint8_t *gathered, uint8_t *cap_out) try {
+  if (!gathered || !cap_out || world < 1 || rate_bits > 3 || cap_h < rate_bits || cap_h > 16 || ((1u << rate_bits) % (unsigned)world) != 0)
+    return P2GPU_E_ARG;
+  const size_t cap_per = ((size_t)1 << cap_h) >> rate_bits, total = (size_t)1 << cap_h;
+  std::vector<dig_t> in(total), cap;
+  memcpy(in.data(), gathered, total * sizeof(dig_t));
+  shard_assemble_cap(world, rate_bits, cap_per, in.data(), cap);
+  for (size_t i = 0; i < total; i++) memcpy(cap_out + 25 * i, cap[i].w, 25);
+  return P2GPU_OK;
+} P2GPU_CATCH
 
 const char *p2gpu_last_error(void) { return g_err.c_str(); }
 

@@ -10,6 +10,8 @@
 // The product path never touches oracle/; without a HIP device every entry
 // point fails with P2GPU_E_DEVICE.
 #include "circuit.hpp"
+#include <rccl/rccl.h>  // types and prototypes only: resolved with dlopen, never linked
+#include <dlfcn.h>
 #include <algorithm>
 #include <chrono>
 #include <cstdarg>
@@ -144,9 +146,56 @@ void flush_kstats(p2gpu_circuit *c) {
 
 uint32_t brev(uint32_t x, unsigned bits) { return bitrev32(x, bits); }
 
-// all-gather over the ranks of a sharded proof (device buffers; the callback is the host side's
-// torch.distributed / RCCL all_gather_into_tensor).  recv = [world][bytes]
+// ---- RCCL, bound at run time -------------------------------------------------------------------
+// The library has no link-time dependency on RCCL: the collectives of a sharded proof resolve
+// librccl.so.1 when sharding is switched on -- the copy that is already mapped into the process when
+// the host side runs torch.distributed (its bundled RCCL has the same SONAME), /opt/rocm's otherwise.
+// Calls are stream-ordered on the circuit's own stream: no host synchronisation around a collective.
+struct RcclApi {
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool ok = false;
+};
+const RcclApi &rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);  // the one the process already uses, if any
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (h) {
+      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+      api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+      api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+      api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
+    }
+  }
+  return api;
+}
+#define RCCL_TRY(expr)                                                                            \
+  do {                                                                                            \
+    ncclResult_t r_ = (expr);                                                                     \
+    if (r_ != ncclSuccess) {                                                                      \
+      set_err("%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(r_), __FILE__, __LINE__);     \
+      return P2GPU_E_DEVICE;                                                                      \
+    }                                                                                             \
+  } while (0)
+
+// all-gather over the ranks of a sharded proof, device buffers, recv = [world][bytes].  With an RCCL
+// communicator (p2gpu_circuit_set_shard_rccl) it is an ncclAllGather enqueued on the circuit's stream;
+// with a host callback (p2gpu_circuit_set_shard: gloo in the CPU-side tests) the stream is drained and
+// the callback returns when the data is in place.
 int shard_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size_t bytes) {
+  if (c->rccl_comm) {
+    RCCL_TRY(rccl().AllGather(send_dev, recv_dev, bytes, ncclUint8, (ncclComm_t)c->rccl_comm, c->stream));
+    return 0;
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   int rc = c->shard_fn(c->shard_ctx, (uint64_t)(uintptr_t)send_dev, (uint64_t)(uintptr_t)recv_dev, (uint64_t)bytes);
   if (rc) {
@@ -155,6 +204,9 @@ int shard_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size
   }
   return 0;
 }
+// does this proof go through the exchange steps?  (world 1 + "shard_exercise": the same code with one
+// rank, which is how the RCCL plumbing is exercised on a single-GPU box)
+bool sharded(const p2gpu_circuit *c) { return c->shard_world > 1 || (c->shard_exercise && (c->rccl_comm || c->shard_fn)); }
 
 int pin_exhausted() {
   set_err("internal: pinned staging arena exhausted");
@@ -214,7 +266,9 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
   const size_t cap_per = m;
   dig_t *raw = c->pin.take<dig_t>(C * cap_per);  // [global coset][cap_per]; pinned: the D2H below is a true async copy
   if (!raw) return pin_exhausted();
-  if (CL == C) {
+  // a tree every rank holds completely (constants/sigmas, FRI steps >= 1) needs no exchange -- except in
+  // the one-rank plumbing test, where every tree goes through the transport
+  if (CL == C && !(c->shard_world == 1 && sharded(c))) {
     HIP_TRY(hipMemcpyAsync(raw, b.dig.p + b.level_off.back(), C * cap_per * sizeof(dig_t), hipMemcpyDeviceToHost,
                            c->stream));
     g_hp.mark("enq(cap)");
@@ -225,18 +279,14 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
     // commitment-time collective: 16 x 25 B in total)
     const size_t bytes = (size_t)CL * cap_per * sizeof(dig_t);
     if (int rc = shard_allgather(c, b.dig.p + b.level_off.back(), c->xchg_recv.p, bytes)) return rc;
-    std::vector<dig_t> all((size_t)c->shard_world * CL * cap_per);
-    HIP_TRY(hipMemcpy(all.data(), c->xchg_recv.p, all.size() * sizeof(dig_t), hipMemcpyDeviceToHost));
-    for (int q = 0; q < c->shard_world; q++)
-      for (uint32_t z = 0; z < CL; z++)
-        for (size_t k = 0; k < cap_per; k++)
-          raw[((size_t)q + (size_t)z * c->shard_world) * cap_per + k] = all[((size_t)q * CL + z) * cap_per + k];
+    dig_t *all = c->pin.take<dig_t>((size_t)c->shard_world * CL * cap_per);
+    if (!all) return pin_exhausted();
+    HIP_TRY(hipMemcpyAsync(all, c->xchg_recv.p, (size_t)c->shard_world * CL * cap_per * sizeof(dig_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    shard_assemble_cap(c->shard_world, c->rate_bits, cap_per, all, b.cap);
+    return 0;
   }
-  unsigned lgC = c->rate_bits, lgp = 0;
-  while (((size_t)1 << lgp) < cap_per) lgp++;
-  b.cap.assign(C * cap_per, dig_t{});
-  for (uint32_t r = 0; r < C; r++)
-    for (uint32_t k = 0; k < cap_per; k++) b.cap[(size_t)brev(r, lgC) * cap_per + brev(k, lgp)] = raw[(size_t)r * cap_per + k];
+  shard_assemble_cap(1, c->rate_bits, cap_per, raw, b.cap);
   return 0;
 }
 
@@ -428,7 +478,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     }
     {
       const gl_t *pr = c->qtmp.p;
-      if (c->shard_world > 1) {
+      if (sharded(c)) {
         // every rank needs all cosets' interpolants for the cross-coset butterflies: all-gather
         // [K][C/world][n] per rank (2 * N * 8 B in total) straight between device buffers
         if (int rc = shard_allgather(c, c->qtmp.p, c->qvals.p, (size_t)K * c->wires.ncl * n * sizeof(gl_t))) return rc;
@@ -589,13 +639,29 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
       if (!pw) return pin_exhausted();
       pw[0] = ~0ull;
       HIP_TRY(hipMemcpyAsync(c->pow_result.p, &pw[0], 8, hipMemcpyHostToDevice, st));
-      {
-        pow_search(st, inter, (uint32_t)ch.n_in, c->pow_bits, base, batch, c->pow_result.p);
+      // sharded: the ranks grind disjoint slices of [base, base + batch) and take the minimum of what
+      // they found; every rank ends with the same, globally minimal witness
+      const bool split = sharded(c);
+      const uint64_t W_ = split ? (uint64_t)c->shard_world : 1, per = (batch + W_ - 1) / W_;
+      const uint64_t my0 = base + per * (uint64_t)(split ? c->shard_rank : 0);
+      const uint64_t myn = my0 >= base + batch ? 0 : std::min(per, base + batch - my0);
+      if (myn) pow_search(st, inter, (uint32_t)ch.n_in, c->pow_bits, my0, myn, c->pow_result.p);
+      if (split) {
+        if (int rc = shard_allgather(c, c->pow_result.p, c->xchg_recv.p, 8)) return rc;
+        unsigned long long *allw = c->pin.take<unsigned long long>((size_t)c->shard_world);
+        if (!allw) return pin_exhausted();
+        HIP_TRY(hipMemcpyAsync(allw, c->xchg_recv.p, 8 * (size_t)c->shard_world, hipMemcpyDeviceToHost, st));
+        g_hp.mark("enq(pow)");
+        HIP_TRY(hipStreamSynchronize(st));
+        g_hp.mark("WAIT(pow)");
+        pw[1] = ~0ull;
+        for (int q = 0; q < c->shard_world; q++) pw[1] = std::min(pw[1], allw[q]);
+      } else {
+        HIP_TRY(hipMemcpyAsync(&pw[1], c->pow_result.p, 8, hipMemcpyDeviceToHost, st));
+        g_hp.mark("enq(pow)");
+        HIP_TRY(hipStreamSynchronize(st));
+        g_hp.mark("WAIT(pow)");
       }
-      HIP_TRY(hipMemcpyAsync(&pw[1], c->pow_result.p, 8, hipMemcpyDeviceToHost, st));
-      g_hp.mark("enq(pow)");
-      HIP_TRY(hipStreamSynchronize(st));
-      g_hp.mark("WAIT(pow)");
       const unsigned long long res = pw[1];
       if (res != ~0ull) {
         pow_witness = res;
@@ -688,7 +754,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   {
     gather_u64(st, c->gather_ptrs.p, (uint32_t)ptrs.size(), c->gather_out.p);
   }
-  if (world == 1) {
+  if (!sharded(c)) {
     HIP_TRY(hipMemcpyAsync(gathered, c->gather_out.p, ptrs.size() * 8, hipMemcpyDeviceToHost, st));
     g_hp.mark("enq(gather)");
     HIP_TRY(hipStreamSynchronize(st));
@@ -698,7 +764,8 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     // from its owner
     if (int rc = shard_allgather(c, c->gather_out.p, c->xchg_recv.p, ptrs.size() * 8)) return rc;
     std::vector<gl_t> all((size_t)world * ptrs.size());
-    HIP_TRY(hipMemcpy(all.data(), c->xchg_recv.p, all.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(all.data(), c->xchg_recv.p, all.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     for (size_t qi = 0; qi < qidx.size(); qi++) {
       const uint32_t owner = brev((uint32_t)(qidx[qi] >> d), lgC) % (uint32_t)world;
       memcpy(&gathered[qi * per_query], &all[(size_t)owner * ptrs.size() + qi * per_query], per_query * 8);
@@ -795,6 +862,8 @@ void circuit_release(p2gpu_circuit *c) {
 void release_for_destroy(p2gpu_circuit *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->rccl_comm) (void)rccl().CommDestroy((ncclComm_t)c->rccl_comm);
+  c->rccl_comm = nullptr;
   circuit_release(c);
 }
 struct ReleaseHook {
@@ -1134,6 +1203,7 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
   std::string k(key);
   if (k == "pow_hint") c->pow_hint = value;
   else if (k == "self_check") c->self_check = (int)value;
+  else if (k == "shard_exercise") c->shard_exercise = (int)value;
   else if (k == "profile") {
     flush_kstats(c);
     c->profile = (int)value;
@@ -1145,17 +1215,17 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
   return P2GPU_OK;
 } P2GPU_CATCH
 
-int p2gpu_circuit_set_shard(p2gpu_circuit *c, int rank, int world, p2gpu_allgather_fn fn, void *ctx) try {
-  if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn) || (c->C % (uint32_t)world) != 0) {
-    set_err("bad shard configuration: rank %d of %d (cosets %u)", rank, world, c ? c->C : 0u);
-    return P2GPU_E_ARG;
-  }
-  if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
+static int shard_layout(p2gpu_circuit *c, int rank, int world) {
   HIP_TRY(hipSetDevice(c->device));
+  if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->rccl_comm) {
+    (void)rccl().CommDestroy((ncclComm_t)c->rccl_comm);
+    c->rccl_comm = nullptr;
+  }
   c->shard_rank = rank;
   c->shard_world = world;
-  c->shard_fn = fn;
-  c->shard_ctx = ctx;
+  c->shard_fn = nullptr;
+  c->shard_ctx = nullptr;
   const uint32_t ncl = c->C / (uint32_t)world;
   const size_t cap_per = ((size_t)1 << c->cap_h) >> c->rate_bits;
   CosetMap cm;
@@ -1176,7 +1246,49 @@ int p2gpu_circuit_set_shard(p2gpu_circuit *c, int rank, int world, p2gpu_allgath
     tree_layout(t0, ncl, c->n >> c->arity[0], cap_per);
   }
   c->xchg_recv.release();
-  if (world > 1) HIP_TRY(c->xchg_recv.alloc((size_t)world * c->gather_cap + 64));
+  // receive side of the largest exchange: quotient interpolants (K * C * n words in total) or the query gather
+  HIP_TRY(c->xchg_recv.alloc(std::max((size_t)world * c->gather_cap, (size_t)c->K * c->C * c->n) + 64));
+  return P2GPU_OK;
+}
+static int shard_args_ok(p2gpu_circuit *c, int rank, int world) {
+  if (!c || world < 1 || rank < 0 || rank >= world || (c->C % (uint32_t)world) != 0) {
+    set_err("bad shard configuration: rank %d of %d (cosets %u)", rank, world, c ? c->C : 0u);
+    return P2GPU_E_ARG;
+  }
+  if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
+  return P2GPU_OK;
+}
+
+int p2gpu_circuit_set_shard(p2gpu_circuit *c, int rank, int world, p2gpu_allgather_fn fn, void *ctx) try {
+  if (int rc = shard_args_ok(c, rank, world)) return rc;
+  if (world > 1 && !fn) { set_err("a host all-gather callback is needed for world > 1 (or use p2gpu_circuit_set_shard_rccl)"); return P2GPU_E_ARG; }
+  if (int rc = shard_layout(c, rank, world)) return rc;
+  c->shard_fn = fn;
+  c->shard_ctx = ctx;
+  return P2GPU_OK;
+} P2GPU_CATCH
+
+int p2gpu_shard_unique_id(uint8_t id_out[128]) try {
+  if (!id_out) return P2GPU_E_ARG;
+  if (int rc = ensure_device()) return rc;
+  if (!rccl().ok) { set_err("librccl.so.1 could not be loaded"); return P2GPU_E_DEVICE; }
+  ncclUniqueId id;
+  static_assert(sizeof id == 128, "ncclUniqueId is 128 bytes");
+  RCCL_TRY(rccl().GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof id);
+  return P2GPU_OK;
+} P2GPU_CATCH
+
+int p2gpu_circuit_set_shard_rccl(p2gpu_circuit *c, int rank, int world, const uint8_t id_in[128]) try {
+  if (int rc = shard_args_ok(c, rank, world)) return rc;
+  if (!id_in) return P2GPU_E_ARG;
+  if (!rccl().ok) { set_err("librccl.so.1 could not be loaded"); return P2GPU_E_DEVICE; }
+  if (int rc = shard_layout(c, rank, world)) return rc;
+  ncclUniqueId id;
+  memcpy(&id, id_in, sizeof id);
+  ncclComm_t comm = nullptr;
+  RCCL_TRY(rccl().CommInitRank(&comm, world, id, rank));
+  c->rccl_comm = (void *)comm;
   return P2GPU_OK;
 } P2GPU_CATCH
 

@@ -10,8 +10,10 @@ Two ways the `prove` path spreads over the GPUs of a node:
   subtrees -- cap entries 2*bitrev3(r) and 2*bitrev3(r)+1 -- so the only exchange a commitment
   needs is an all-gather of 16 x 25-byte cap entries (`all_gather_cap`), after which every rank
   runs the Fiat-Shamir transcript replicated.  This mode is implemented inside the library
-  (`CircuitData.set_shard(rank, world)` -> p2gpu_circuit_set_shard); the helpers below state the
-  ownership map and are what the CPU-only gloo test exercises.
+  (`CircuitData.set_shard(rank, world)` -> p2gpu_circuit_set_shard_rccl: RCCL called by the library on
+  its own stream).  `local_roots` / `owned_cap_entries` restate the ownership map in Python;
+  `all_gather_cap` runs the same exchange with torch.distributed as the transport and the library's own
+  cap assembly (p2gpu_shard_assemble_cap) -- which is what the CPU-only gloo test exercises.
 """
 import numpy as np
 
@@ -45,24 +47,43 @@ def owned_cap_entries(world_size, rank, rate_bits=3, cap_height=4):
     return out
 
 
-def all_gather_cap(local_entries, world_size, rank, rate_bits=3, cap_height=4, group=None):
-    """Reassemble a Merkle cap from each rank's owned entries (bytes, 25 B per entry, in the
-    order of `owned_cap_entries`).  One small all-gather; returns the full cap bytes."""
+def local_roots(full_cap, world_size, rank, rate_bits=3, cap_height=4):
+    """The subtree roots rank `rank` holds after building its cosets' trees, cut out of a complete cap
+    (bytes, 25 B per entry): [local coset z][k] -> cap entry bitrev(rank + z * world) * per + bitrev(k),
+    each padded to the 32 B a digest occupies in device memory.  (What a rank sends into the all-gather.)"""
+    per = 1 << (cap_height - rate_bits)
+    lgp = cap_height - rate_bits
+    out = bytearray()
+    for r in owned_cosets(world_size, rank, rate_bits):
+        for k in range(per):
+            idx = _bitrev(r, rate_bits) * per + _bitrev(k, lgp)
+            out += full_cap[25 * idx:25 * idx + 25] + bytes(7)
+    return bytes(out)
+
+
+def all_gather_cap(local_roots32, world_size, rank, rate_bits=3, cap_height=4, group=None):
+    """The commitment-time collective of a coset-sharded proof with torch.distributed as the transport:
+    all-gather every rank's local subtree roots (32 B each, `local_roots` order) and let the LIBRARY put
+    the cap into plonky2 order -- p2gpu_shard_assemble_cap is the same host code the prover's own
+    exchange path runs after its ncclAllGather (csrc/hostcore.hip shard_assemble_cap)."""
+    import ctypes
+
     import torch
     import torch.distributed as dist
 
-    n_own = len(owned_cap_entries(world_size, rank, rate_bits, cap_height))
-    assert len(local_entries) == 25 * n_own
+    from .prover import _check, load_library
+
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    mine = torch.frombuffer(bytearray(local_entries), dtype=torch.uint8).to(dev)
+    mine = torch.frombuffer(bytearray(local_roots32), dtype=torch.uint8).to(dev)
     gathered = torch.empty(world_size * mine.numel(), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(gathered, mine, group=group)
-    g = gathered.cpu().numpy().reshape(world_size, n_own, 25)
-    cap = np.zeros((1 << cap_height, 25), dtype=np.uint8)
-    for q in range(world_size):
-        for j, idx in enumerate(owned_cap_entries(world_size, q, rate_bits, cap_height)):
-            cap[idx] = g[q, j]
+    g = np.ascontiguousarray(gathered.cpu().numpy())
+    assert g.size == 32 << cap_height
+    cap = np.zeros(25 << cap_height, dtype=np.uint8)
+    lib = load_library()
+    lib.p2gpu_shard_assemble_cap.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]
+    _check(lib.p2gpu_shard_assemble_cap(world_size, rate_bits, cap_height, g.ctypes.data, cap.ctypes.data))
     return cap.tobytes()
 
 

@@ -97,6 +97,8 @@ def load_library():
     lib.p2gpu_verify_compressed.argtypes = [vp, u8p, sz]
     lib.p2gpu_circuit_set.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64]
     lib.p2gpu_circuit_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int, _ALLGATHER_FN, vp]
+    lib.p2gpu_shard_unique_id.argtypes = [vp]
+    lib.p2gpu_circuit_set_shard_rccl.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
     lib.p2gpu_kernel_stats.argtypes = [vp, ctypes.c_char_p, vp, vp, vp, ctypes.c_int]
     lib.p2gpu_ifft_batch.argtypes = [vp, sz, ctypes.c_uint, vp]
     lib.p2gpu_lde_batch.argtypes = [vp, sz, ctypes.c_uint, ctypes.c_uint, vp]
@@ -186,16 +188,40 @@ class CircuitData:
     def set(self, key, value):
         _check(self._lib.p2gpu_circuit_set(self._h, key.encode(), ctypes.c_uint64(value)))
 
-    def set_shard(self, rank, world, group=None):
-        """Coset-shard every following proof over the `world` ranks of `group` (one process per
-        GPU; torch.distributed must be initialised).  The library hands device buffers to the
-        all-gather below: with the nccl backend (= RCCL over xGMI) they are gathered in place,
-        with gloo (CPU tests) they are staged through host tensors."""
+    def set_shard(self, rank, world, group=None, transport=None):
+        """Coset-shard every following proof over the `world` ranks of `group` (one process per GPU;
+        torch.distributed must be initialised when world > 1).
+
+        transport "rccl" (default whenever the process group's backend is nccl): the library itself
+        calls RCCL (ncclAllGather on its own HIP stream, xGMI on a real node) -- torch.distributed is used
+        once, to broadcast the 128-byte ncclUniqueId.  transport "callback" (default for gloo, i.e. the
+        CPU-side tests): the library hands device buffers to a host callback that gathers them with
+        torch.distributed, staging through host tensors."""
         import torch
         import torch.distributed as dist
 
+        backend = dist.get_backend(group) if (world > 1 or (dist.is_available() and dist.is_initialized())) else None
+        if transport is None:
+            transport = "rccl" if backend == "nccl" else "callback"
+        if transport == "rccl":
+            idbuf = np.zeros(128, dtype=np.uint8)
+            if rank == 0:
+                _check(self._lib.p2gpu_shard_unique_id(idbuf.ctypes.data))
+            if world > 1:
+                if backend == "nccl":
+                    t = torch.from_numpy(idbuf).cuda()
+                    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                    idbuf = t.cpu().numpy()
+                else:
+                    t = torch.from_numpy(idbuf)
+                    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                    idbuf = t.numpy()
+            idbuf = np.ascontiguousarray(idbuf)
+            _check(self._lib.p2gpu_circuit_set_shard_rccl(self._h, rank, world, idbuf.ctypes.data))
+            self._shard_cb = None
+            self.shard = (rank, world)
+            return
         if world > 1:
-            backend = dist.get_backend(group)
 
             def _allgather(_ctx, send, recv, nbytes):
                 try:

@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--cpu-single-thread-bits", type=int, default=12,
                     help="degree bits of the one-thread oracle sample (0 = skip the one-thread leg)")
     ap.add_argument("--profile-steps", type=int, default=4)
+    ap.add_argument("--timed-only", action="store_true",
+                    help="warm-up + timed region only (no host-witness / pipelined / event-profile / CPU passes): the command "
+                         "rocprofv3 wraps (scratch/prof.sh), so that its per-kernel averages are those of the timed path")
     args = ap.parse_args()
 
     import torch
@@ -216,8 +219,9 @@ def main():
     pis = made[2] if args.public_inputs else ()
     S = 1 if sharded else max(1, min(args.in_flight, args.steps))
     cds = [pkg.CircuitData(blob) for _ in range(S)]
-    if sharded:
-        cds[0].set_shard(rank, world)
+    if args.mode == "sharded":
+        # world 1: same code path as a replica (nothing to exchange); world > 1: RCCL inside the library
+        cds[0].set_shard(rank, world, transport="rccl" if args.backend == "nccl" else None)
     wires_dev = torch.from_numpy(wires.view(np.int64)).cuda()
     torch.cuda.synchronize()
 
@@ -265,6 +269,18 @@ def main():
         for k, v in t.items():
             if k.endswith("_ms"):
                 phase[k] = phase.get(k, 0.0) + v
+
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"metric": f"proofs/sec at 2^{d + 3} LDE rows (prove latency = ms_per_step)", "value": (args.steps if sharded else world * args.steps) / dt,
+                              "unit": "proofs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                              "proofs_in_process": args.steps + max(args.warmup, S), "timed_only": True}), flush=True)
+        for c_ in cds:
+            c_.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- separate passes (not part of `value`) ----
     cd = cds[0]

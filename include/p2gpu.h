@@ -154,7 +154,8 @@ int p2gpu_verify_compressed(const p2gpu_circuit *c, const uint8_t *cproof, size_
 
 /* optional knobs: "pow_hint" (u64; UINT64_MAX = grind), "self_check" (0/1, default 1: evaluate the
  * verifier's plonk identity at zeta on the host before FRI and return P2GPU_E_UNSATISFIED when the
- * witness does not satisfy the circuit; 0 = emit the proof anyway like upstream), "profile" (0 / 1 / 2: time kernel
+ * witness does not satisfy the circuit; 0 = emit the proof anyway like upstream), "shard_exercise" (0/1: with world = 1, still run the exchange steps of a sharded proof through the
+ * configured transport -- how the RCCL path is tested on a one-GPU machine), "profile" (0 / 1 / 2: time kernel
  * launches with HIP events on the launch stream -- 1 = the launches that move >= 32 MB, 2 = every launch;
  * resets the statistics) */
 int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value);
@@ -173,6 +174,19 @@ int p2gpu_kernel_stats(p2gpu_circuit *c, char *names, double *ms, double *bytes,
  * `bytes` from every rank's send buffer into recv_dev[rank * bytes ...] and return 0 when done. */
 typedef int (*p2gpu_allgather_fn)(void *ctx, uint64_t send_dev, uint64_t recv_dev, uint64_t bytes_per_rank);
 int p2gpu_circuit_set_shard(p2gpu_circuit *c, int rank, int world, p2gpu_allgather_fn fn, void *ctx);
+/* The same with RCCL inside the library (the production transport on a multi-GPU node: xGMI): rank 0
+ * obtains a 128-byte id (ncclGetUniqueId), the host side broadcasts it to the other ranks by any means
+ * (torch.distributed, MPI, a file), every rank then calls p2gpu_circuit_set_shard_rccl with its rank.
+ * The collectives (ncclAllGather) are enqueued on the circuit's own HIP stream -- no host synchronisation
+ * around them.  RCCL is resolved with dlopen("librccl.so.1") at this point, not at link time: the copy
+ * the process already uses (torch's) is taken when there is one. */
+int p2gpu_shard_unique_id(uint8_t id_out[128]);
+/* Host-only piece of the sharded commitment, exposed for callers that run the exchange themselves and for
+ * the CPU-side tests: the Merkle cap in plonky2 order (2^cap_h x 25 B) from the all-gather of every rank's
+ * local subtree roots, gathered = [world][2^rate_bits / world local cosets][2^(cap_h - rate_bits)] digests
+ * of 32 B (25 used); rank q's local coset z is the global coset q + z * world. */
+int p2gpu_shard_assemble_cap(int world, unsigned rate_bits, unsigned cap_h, const uint8_t *gathered, uint8_t *cap_out);
+int p2gpu_circuit_set_shard_rccl(p2gpu_circuit *c, int rank, int world, const uint8_t id[128]);
 
 /* stage-level operators (host buffers in/out; used by the parity tests) */
 /* values [ncols][2^d] -> coefficients [ncols][2^d], natural order */

@@ -59,7 +59,7 @@ def main():
         }
     with open(os.path.join(here, f"{tag}_pmc_summary.json"), "w") as fo:
         json.dump({"note": "bytes = KiB * 1024; read side doubled (gfx950 FETCH_SIZE correction); separate --pmc passes",
-                   "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline (scratch/prof.sh)", "kernels": out}, fo, indent=1)
+                   "command": "python bench.py --steps 5 --warmup 2 --timed-only [+ workload flags] (scratch/prof.sh): 7 proofs + one circuit creation", "kernels": out}, fo, indent=1)
     # SQ counters (one more --pmc pass): where the waves' cycles go -- VALU issue vs waiting
     sq_names = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
                 "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES"]
@@ -76,6 +76,9 @@ def main():
         with open(os.path.join(here, f"{tag}_sq_summary.json"), "w") as fo:
             json.dump({"note": "per-launch averages of SQ counters (quad-cycle units summed over waves); fractions are of SQ_WAVE_CYCLES",
                        "kernels": sq}, fo, indent=1)
+    # whole-run totals: 7 proofs (2 warm-up + 5 timed) + one circuit creation in the profiled process
+    tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
+    print(f"HBM traffic of the whole process: {tot / 1e9:.2f} GB = {tot / 7 / 1e9:.2f} GB per proof (7 proofs + circuit creation)")
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
         print(f"{k:32s} n={v['launches']:4d} read {v['hbm_read_bytes_per_launch']/1e6:10.1f} MB  write {v['hbm_write_bytes_per_launch']/1e6:10.1f} MB")
 

@@ -1,15 +1,21 @@
 #!/bin/bash
-# rocprofv3 recipe (guide: cd /tmp && export TMPDIR=/tmp first); outputs under gpurun_out/prof_*
+# rocprofv3 recipe (guide: cd /tmp && export TMPDIR=/tmp first); outputs under gpurun_out/prof_<tag>
+#   bash scratch/prof.sh <tag> [extra bench.py args]     e.g.  bash scratch/prof.sh r02b_ecdsa --mix ecdsa
+# Four separate passes of the SAME command: --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE; SQ counters
+# (counter passes never combined with the trace domains gpurun refuses).
 set -x
 REPO=$(pwd)
 export TMPDIR=/tmp
 cd /tmp
-OUT=$REPO/gpurun_out/prof_${1:-run}
+TAG=${1:-run}; shift
+OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-CMD="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps 5 --warmup 2 --timed-only $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/sq -- $CMD > $OUT/sq.log 2>&1
 cd $REPO
+# keep what travels back small: the per-dispatch CSVs are large
+find $OUT -name "*_agent_info.csv" -delete
 du -sh $OUT

@@ -43,9 +43,9 @@ def _worker(rank, world, port, q):
     # (2) cap all-gather of the coset-sharded scheme
     blob, wires = pkg.make_circuit(5, "sha", seed=3)
     full = orc.commit_values(wires[:20], 3, 4)
-    own = par.owned_cap_entries(world, rank)
-    local = b"".join(full[25 * i: 25 * i + 25] for i in own)
-    cap = par.all_gather_cap(local, world, rank)
+    # each rank contributes the subtree roots of ITS cosets (Python restatement of the ownership map);
+    # the library's own host code (p2gpu_shard_assemble_cap, used by the prover's exchange path) orders them
+    cap = par.all_gather_cap(par.local_roots(full, world, rank), world, rank)
     t = par.max_over_ranks(float(rank + 1))
     dist.barrier()
     dist.destroy_process_group()
@@ -86,3 +86,17 @@ def test_partition_and_ownership(pkg):
         owned = sorted(sum((par.owned_cap_entries(w, r) for r in range(w)), []))
         assert owned == list(range(16))
     assert par.owned_cap_entries(8, 1) == [8, 9]  # coset 1 -> bitrev3(1) = 4 -> entries 8, 9
+    # library assembly (product code) vs the Python ownership map, for every world size, no collective needed
+    import ctypes
+
+    import numpy as np
+
+    lib = pkg.load_library()
+    lib.p2gpu_shard_assemble_cap.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]
+    full = bytes(np.random.default_rng(5).integers(0, 256, size=25 * 16, dtype=np.uint8))
+    for w in (1, 2, 4, 8):
+        g = np.frombuffer(b"".join(par.local_roots(full, w, r) for r in range(w)), dtype=np.uint8).copy()
+        out = np.zeros(25 * 16, dtype=np.uint8)
+        assert lib.p2gpu_shard_assemble_cap(w, 3, 4, g.ctypes.data, out.ctypes.data) == 0
+        assert out.tobytes() == full
+    assert lib.p2gpu_shard_assemble_cap(3, 3, 4, g.ctypes.data, out.ctypes.data) != 0  # 8 cosets over 3 ranks

@@ -12,6 +12,7 @@ with ``__graft_entry__.load_package()`` which registers it as
 """
 from .prover import (  # noqa: F401
     CircuitData,
+    build_blob,
     VerifierCircuitData,
     ProofWithPublicInputs,
     P2GpuError,

@@ -226,6 +226,150 @@ int p2gpu_shard_assemble_cap(int world, unsigned rate_bits, unsigned cap_h, cons
   return P2GPU_OK;
 } P2GPU_CATCH
 
+// ---- N2: the prover-side precompute of `builder.build::<C>()` that needs no GPU -----------------------
+// (plonky2-backend/src/circuit_translation/mod.rs:80-82, actions/write_vk_action.rs:76): from the gate
+// instances (one gate index and the gate's constants per row) and the copy constraints it derives
+//   * the selector columns and selector groups (plonky2 gates/selectors.rs selector_polynomials: gates come
+//     sorted by (degree, id); one column when max_degree >= max gate degree + #gates - 1, greedy groups of
+//     gates[start..start+size) with size + degree(gates[start + size]) < max_degree otherwise; a row of a
+//     gate outside the group holds UNUSED = 2^32 - 1),
+//   * the sigma polynomials of the permutation argument (plonk/permutation_argument.rs: union-find over the
+//     routed cells, every class listed row by row, each cell mapped to the next of its class; as values
+//     k_is[col'] * w_n^row'), k_is[j] = g^j,
+//   * the FRI reduction arities of ConstantArityBits(4, 5),
+// and writes the circuit blob that p2gpu_circuit_create takes (which then commits constants and sigmas on the
+// GPU and derives the circuit digest).  Pinned to the reference: the circuits recovered from its own proof
+// files come back bit for bit (tests/test_build.py).
+int p2gpu_build_blob(const p2gpu_build_params *bp, const p2gpu_gate_decl *gates, uint32_t num_gates, const uint32_t *row_gate,
+                     const uint64_t *row_constants, const uint32_t *copies, size_t num_copies, uint8_t *blob_out,
+                     size_t *blob_len) try {
+  if (!bp || !gates || !row_gate || !blob_len || (num_copies && !copies)) return P2GPU_E_ARG;
+  const uint32_t d = bp->degree_bits, W = bp->num_wires, R = bp->num_routed_wires, QF = bp->quotient_degree_factor;
+  if (d < 1 || d > 24 || num_gates == 0 || num_gates > (uint32_t)MAX_GATES || R == 0 || R > (uint32_t)MAX_ROUTED || W < R || W > 4096 ||
+      QF == 0 || bp->rate_bits < 1 || bp->rate_bits > 3 || (1u << bp->rate_bits) != QF || bp->num_challenges < 1 ||
+      bp->num_challenges > 2) {
+    set_err("p2gpu_build_blob: unsupported circuit parameters");
+    return P2GPU_E_ARG;
+  }
+  const size_t n = (size_t)1 << d;
+  for (uint32_t i = 1; i < num_gates; i++)
+    if (gates[i].degree < gates[i - 1].degree) {
+      set_err("p2gpu_build_blob: gates must come sorted by (degree, id) as in CommonCircuitData.gates");
+      return P2GPU_E_ARG;
+    }
+  // selector groups
+  const uint32_t max_degree = QF + 1;
+  std::vector<uint32_t> gstart(num_gates), gend(num_gates), gsel(num_gates);
+  uint32_t num_selectors = 0;
+  if (gates[num_gates - 1].degree + num_gates - 1 <= max_degree) {
+    num_selectors = 1;
+    for (uint32_t i = 0; i < num_gates; i++) { gstart[i] = 0; gend[i] = num_gates; gsel[i] = 0; }
+  } else {
+    uint32_t start = 0;
+    while (start < num_gates) {
+      uint32_t size = 0;
+      while (start + size < num_gates && size + gates[start + size].degree < max_degree) size++;
+      if (size == 0) { set_err("p2gpu_build_blob: gate degree %u does not fit max_degree %u", gates[start].degree, max_degree); return P2GPU_E_ARG; }
+      for (uint32_t i = start; i < start + size; i++) { gstart[i] = start; gend[i] = start + size; gsel[i] = num_selectors; }
+      start += size;
+      num_selectors++;
+    }
+  }
+  uint32_t ngc = 0;
+  for (uint32_t i = 0; i < num_gates; i++) ngc = std::max(ngc, gates[i].num_constants);
+  if (ngc && !row_constants) return P2GPU_E_ARG;
+  const uint32_t NC = num_selectors + ngc;
+  std::vector<uint32_t> arity;
+  for (uint32_t db = d; db > 5 && db + bp->rate_bits - 4 >= bp->cap_height; db -= 4) arity.push_back(4);
+  if (arity.size() > 8) return P2GPU_E_ARG;
+  const size_t need = 256 + 48 * (size_t)num_gates + 8 * ((size_t)R + (size_t)NC * n + (size_t)R * n);
+  if (!blob_out || *blob_len < need) {
+    const bool probe = blob_out == nullptr;
+    *blob_len = need;
+    if (probe) return P2GPU_OK;
+    set_err("blob buffer too small: need %zu bytes", need);
+    return P2GPU_E_BUFFER;
+  }
+  // header + gate table
+  uint32_t hd[64];
+  memset(hd, 0, sizeof hd);
+  hd[0] = 0x43473250u; hd[1] = 1; hd[2] = d; hd[3] = W; hd[4] = R; hd[5] = NC; hd[6] = num_selectors; hd[7] = bp->num_challenges;
+  hd[8] = QF; hd[9] = bp->rate_bits; hd[10] = bp->cap_height; hd[11] = bp->proof_of_work_bits; hd[12] = bp->num_query_rounds;
+  hd[13] = (uint32_t)arity.size();
+  for (size_t i = 0; i < arity.size(); i++) hd[14 + i] = arity[i];
+  hd[22] = 0; hd[23] = num_gates; hd[24] = bp->num_public_inputs; hd[25] = 0; hd[26] = (R + QF - 1) / QF - 1;
+  memcpy(blob_out, hd, sizeof hd);
+  size_t off = sizeof hd;
+  for (uint32_t i = 0; i < num_gates; i++) {
+    uint64_t wu = 0;
+    uint32_t cu = 0;
+    if (gates[i].kind >= G_KIND_COUNT) { set_err("unsupported gate kind in blob"); return P2GPU_E_ARG; }
+    if (const char *why = gate_validate(gates[i].kind, gates[i].p, W, ngc, &wu, &cu)) { set_err("%s", why); return P2GPU_E_ARG; }
+    const uint32_t gw[12] = {gates[i].kind, gates[i].p[0], gates[i].p[1], gates[i].p[2], gates[i].p[3], gsel[i], gstart[i], gend[i],
+                             gate_num_constraints(gates[i].kind, gates[i].p), gates[i].degree, gates[i].num_constants, 0};
+    memcpy(blob_out + off, gw, sizeof gw);
+    off += sizeof gw;
+  }
+  // k_is and the subgroup
+  std::vector<gl_t> k_is(R), sub(n);
+  k_is[0] = 1;
+  for (uint32_t j = 1; j < R; j++) k_is[j] = gl_mul(k_is[j - 1], GL_GEN);
+  {
+    const gl_t wn = gl_root(d);
+    sub[0] = 1;
+    for (size_t i = 1; i < n; i++) sub[i] = gl_mul(sub[i - 1], wn);
+  }
+  memcpy(blob_out + off, k_is.data(), 8 * (size_t)R);
+  off += 8 * (size_t)R;
+  // constants: selector columns, then the gate constants as given
+  gl_t *consts = (gl_t *)(blob_out + off);  // (8-byte aligned: 256 + 48 g + 8 R)
+  for (size_t r = 0; r < n; r++) {
+    const uint32_t gi = row_gate[r];
+    if (gi >= num_gates) { set_err("row %zu holds gate index %u of %u", r, gi, num_gates); return P2GPU_E_ARG; }
+    for (uint32_t s = 0; s < num_selectors; s++) consts[(size_t)s * n + r] = (num_selectors == 1 || s == gsel[gi]) ? gi : 0xFFFFFFFFull;
+  }
+  for (uint32_t k = 0; k < ngc; k++)
+    for (size_t r = 0; r < n; r++) {
+      const uint64_t v = row_constants[(size_t)k * n + r];
+      if (v >= GL_P) { set_err("gate constant (%u, %zu) is not canonical", k, r); return P2GPU_E_ARG; }
+      consts[(size_t)(num_selectors + k) * n + r] = v;
+    }
+  off += 8 * (size_t)NC * n;
+  // sigma from the copy constraints
+  gl_t *sig = (gl_t *)(blob_out + off);
+  {
+    const size_t tot = (size_t)R * n;
+    std::vector<uint32_t> parent(tot);
+    for (size_t x = 0; x < tot; x++) parent[x] = (uint32_t)x;
+    auto find = [&](uint32_t x) {
+      while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
+      return x;
+    };
+    for (size_t e = 0; e < num_copies; e++) {
+      const uint32_t ra = copies[4 * e], ca = copies[4 * e + 1], rb = copies[4 * e + 2], cb = copies[4 * e + 3];
+      if (ra >= n || rb >= n || ca >= R || cb >= R) { set_err("copy constraint %zu names a cell outside the routed wires", e); return P2GPU_E_ARG; }
+      const uint32_t x = find((uint32_t)((size_t)ca * n + ra)), y = find((uint32_t)((size_t)cb * n + rb));
+      if (x != y) parent[std::max(x, y)] = std::min(x, y);
+    }
+    std::vector<uint32_t> first(tot, UINT32_MAX), last(tot, UINT32_MAX), next(tot);
+    for (size_t row = 0; row < n; row++)
+      for (uint32_t col = 0; col < R; col++) {
+        const uint32_t x = (uint32_t)((size_t)col * n + row), rt = find(x);
+        if (first[rt] == UINT32_MAX) first[rt] = x;
+        else next[last[rt]] = x;
+        last[rt] = x;
+      }
+    for (size_t x = 0; x < tot; x++) {
+      const uint32_t rt = find((uint32_t)x);
+      if (last[rt] == x) next[x] = first[rt];
+    }
+    for (size_t x = 0; x < tot; x++) sig[x] = gl_mul(k_is[next[x] / n], sub[next[x] % n]);
+  }
+  off += 8 * (size_t)R * n;
+  *blob_len = off;
+  return P2GPU_OK;
+} P2GPU_CATCH
+
 const char *p2gpu_last_error(void) { return g_err.c_str(); }
 
 size_t p2gpu_proof_size_bound(const p2gpu_circuit *c) {

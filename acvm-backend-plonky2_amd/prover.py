@@ -416,6 +416,46 @@ class VerifierCircuitData(_ProofFormats):
             pass
 
 
+# ---- build(): the GPU-free precompute + circuit creation -----------------------
+class _BuildParams(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_uint32) for k in ("degree_bits", "num_wires", "num_routed_wires", "num_challenges", "quotient_degree_factor",
+                                                "rate_bits", "cap_height", "proof_of_work_bits", "num_query_rounds", "num_public_inputs")]
+
+
+class _GateDecl(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_uint32), ("p", ctypes.c_uint32 * 4), ("degree", ctypes.c_uint32), ("num_constants", ctypes.c_uint32)]
+
+
+def build_blob(degree_bits, gates, row_gate, row_constants, copies, num_public_inputs=0, num_wires=234, num_routed_wires=80,
+               num_challenges=2, quotient_degree_factor=8, rate_bits=3, cap_height=4, proof_of_work_bits=16, num_query_rounds=28):
+    """``builder.build::<C>()`` minus the GPU part (circuit_translation/mod.rs:80-82): selector columns and groups,
+    sigma polynomials from the copy constraints, k_is, FRI arities -> circuit blob (p2gpu_build_blob).
+    gates: [(kind, (p0, p1, p2, p3), degree, num_constants)] sorted by (degree, id) like CommonCircuitData.gates;
+    row_gate[n]; row_constants[max num_constants][n]; copies[m][4] = (row_a, col_a, row_b, col_b).
+    ``CircuitData(build_blob(...))`` then commits constants and sigmas on the GPU and derives the digest."""
+    lib = load_library()
+    lib.p2gpu_build_blob.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    bp = _BuildParams(degree_bits, num_wires, num_routed_wires, num_challenges, quotient_degree_factor, rate_bits, cap_height,
+                      proof_of_work_bits, num_query_rounds, num_public_inputs)
+    gd = (_GateDecl * len(gates))()
+    for i, (kind, ps, deg, nk) in enumerate(gates):
+        gd[i].kind, gd[i].degree, gd[i].num_constants = kind, deg, nk
+        for j, v in enumerate(tuple(ps) + (0,) * (4 - len(ps))):
+            gd[i].p[j] = v
+    rg = np.ascontiguousarray(row_gate, dtype=np.uint32)
+    rc = np.ascontiguousarray(row_constants, dtype=np.uint64)
+    cp = np.ascontiguousarray(copies, dtype=np.uint32).reshape(-1, 4)
+    if rg.size != 1 << degree_bits:
+        raise P2GpuError(-7, "row_gate must have 2^degree_bits entries")
+    ln = ctypes.c_size_t(0)
+    args = [ctypes.byref(bp), gd, len(gates), rg.ctypes.data, rc.ctypes.data if rc.size else None, cp.ctypes.data if cp.size else None, len(cp)]
+    _check(lib.p2gpu_build_blob(*args, None, ctypes.byref(ln)))
+    out = np.zeros(ln.value, dtype=np.uint8)
+    _check(lib.p2gpu_build_blob(*args, out.ctypes.data, ctypes.byref(ln)))
+    return out[:ln.value]
+
+
 # ---- stage-level operators ---------------------------------------------------
 def ifft_batch(vals):
     """PolynomialValues::ifft on every row of `vals` [ncols][2^d]."""

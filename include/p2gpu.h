@@ -128,6 +128,26 @@ int p2gpu_fill_witness(p2gpu_circuit *c, uint64_t *wires_dev);
 int p2gpu_prove_routed(p2gpu_circuit *c, const uint64_t *routed, const uint64_t *public_inputs, uint32_t n_pi,
                        uint8_t *proof_out, size_t *proof_len, p2gpu_timings *opt_timings);
 
+/* ---- N2: prover-side precompute of `builder.build::<C>()` (host code; circuit_translation/mod.rs:80-82) ----
+ * From the gate instances and the copy constraints: selector columns + groups (gates/selectors.rs), the
+ * sigma polynomials (plonk/permutation_argument.rs WirePartition), k_is and the FRI arities; output is the
+ * circuit blob for p2gpu_circuit_create, which does the GPU part (constants/sigmas commitment, digest).
+ *   gates:  in CommonCircuitData.gates order, i.e. sorted by (degree, id); kind / p as in the blob
+ *   row_gate[n]: index into `gates` of the gate instance on each row
+ *   row_constants[max num_constants][n]: the gate constants of each row, column-major (NULL if no gate has any)
+ *   copies[num_copies][4]: (row_a, col_a, row_b, col_b) pairs of routed cells that must be equal
+ * blob_out == NULL: only report the size in *blob_len. */
+typedef struct {
+  uint32_t degree_bits, num_wires, num_routed_wires, num_challenges, quotient_degree_factor, rate_bits, cap_height,
+      proof_of_work_bits, num_query_rounds, num_public_inputs;
+} p2gpu_build_params;
+typedef struct {
+  uint32_t kind, p[4], degree, num_constants;
+} p2gpu_gate_decl;
+int p2gpu_build_blob(const p2gpu_build_params *params, const p2gpu_gate_decl *gates, uint32_t num_gates, const uint32_t *row_gate,
+                     const uint64_t *row_constants, const uint32_t *copies, size_t num_copies, uint8_t *blob_out,
+                     size_t *blob_len);
+
 /* ---- verification (host code only; needs no GPU) ------------------------------------------------
  * The counterpart of the reference's `verify` action (plonky2-backend/src/actions/verify_action.rs:11-17)
  * and of the `circuit_data.verify(proof)` assertion its tests end with (tests/factories/utils.rs:26-27),

@@ -68,6 +68,18 @@ int orc_verify(const orc_circuit *c, const uint8_t *proof, size_t len, orc_trace
  * from the gate's input wires; wires [num_wires][n] in place */
 int orc_fill_witness(const orc_circuit *c, uint64_t *wires);
 
+/* the GPU-free part of build(): selectors, sigma, k_is, FRI arities -> circuit blob (build.c).  Same argument
+ * meaning as the product's p2gpu_build_blob (include/p2gpu.h). */
+typedef struct {
+  uint32_t degree_bits, num_wires, num_routed_wires, num_challenges, quotient_degree_factor, rate_bits, cap_height,
+      proof_of_work_bits, num_query_rounds, num_public_inputs;
+} orc_build_params;
+typedef struct {
+  uint32_t kind, p[4], degree, num_constants;
+} orc_gate_decl;
+int orc_build_blob(const orc_build_params *bp, const orc_gate_decl *gates, uint32_t num_gates, const uint32_t *row_gate,
+                   const uint64_t *row_constants, const uint32_t *copies, size_t num_copies, uint8_t *out, size_t *len);
+
 /* stage-level entry points for parity tests */
 void orc_ntt(uint64_t *a, unsigned lg, int inverse);
 void orc_coset_lde(const uint64_t *coeffs, unsigned d, unsigned rate_bits, uint64_t *out /* 2^(d+rate_bits), natural */);

@@ -489,7 +489,9 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     A.tiles = tiles; A.cols_grid = cols; A.cosets = cosets;
     dim3 grid((((tiles * cols + 7u) / 8u) * 8u) * cosets);
     const uint32_t threads = TB >= 8 ? 256 : 64;
-    const double bytes = 16.0 * ((double)cols * cosets * ((size_t)1 << d));
+    // expected HBM bytes: every output element is written once; the input is read once per element, except
+    // that the cosets of one (tile, column) share their source through one XCD's L2 (first LDE pass)
+    const double bytes = 8.0 * (double)cols * ((size_t)1 << d) * (cosets + (A.src_single ? 1.0 : (double)cosets));
     // same spelling as rocprofv3's demangled kernel names, so the bench line and profiles/ agree
     const char *name;
     if (TB == NTT_TILE_BITS)

@@ -374,7 +374,7 @@ def main():
                 "algorithmic_bytes_definition": f"SURVEY.md 8(d) bytes of prover step '{step}' ({steps_b.get(step, 0) / 1e9:.3f} GB per proof) "
                                                 f"/ launches of that step per proof",
                 "implementation_bytes_per_launch": impl_per_launch,
-                "frac_traffic": gbps_impl / HBM_PEAK_GBPS,
+                "frac_traffic": (traffic / (avg_ms * 1e-3) / 1e9 if traffic else gbps_impl) / HBM_PEAK_GBPS,
                 "whole_proof": {"algorithmic_bytes": total_b, "achieved": total_b / (ms_step * 1e-3) / 1e9, "unit": "GB/s",
                                 "frac": total_b / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                 "note": "B(N) / t_prove of SURVEY.md 8(d); the prover is VALU-issue-bound, see `issue`"},

@@ -160,6 +160,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--degree-bits", type=int, default=17)
     ap.add_argument("--mix", default="sha")
+    ap.add_argument("--workload", choices=["synth", "sha256"], default="synth",
+                    help="synth: synthetic circuit with the reference's shape (SURVEY 8(d)); sha256: the circuit the reference's "
+                         "translator builds for --sha-blocks chained Sha256Compression opcodes (translate.py; 4 blocks = 2^17 gates "
+                         "= 2^20 LDE rows; translating takes ~15 s per block in Python, outside every timed region)")
+    ap.add_argument("--sha-blocks", type=int, default=4)
     ap.add_argument("--public-inputs", type=int, default=0,
                     help="public inputs of the synthetic circuit (> 0 adds PoseidonGate rows to the circuit and the "
                          "PoseidonGate to the gate set every LDE row evaluates); 0 = the BASELINE parity shape")
@@ -214,9 +219,30 @@ def main():
     d, mix = args.degree_bits, args.mix
     # every rank proves its own witness of the same circuit shape (independent proofs)
     sharded = args.mode == "sharded" and world > 1
-    made = pkg.make_circuit(d, mix, seed=1 if sharded else 1 + rank, num_public_inputs=args.public_inputs)
-    blob, wires = made[0], made[1]
-    pis = made[2] if args.public_inputs else ()
+    if args.workload == "sha256":
+        # a message of --sha-blocks 64-byte blocks hashed by chained compression opcodes (each one's output state
+        # is the next one's hash_values), through the restated translator; every rank hashes its own message
+        cb = pkg.translate.CircuitBuilderFromAcirToPlonky2()
+        nb = args.sha_blocks
+        ops, w0 = [], 24 * 0
+        state_w = list(range(16 * nb, 16 * nb + 8))
+        nxt = 16 * nb + 8
+        for i in range(nb):
+            outs = list(range(nxt, nxt + 8))
+            ops.append(("sha256_compression", list(range(16 * i, 16 * i + 16)), state_w, outs))
+            state_w, nxt = outs, nxt + 8
+        cb.translate_circuit(ops)
+        rng = np.random.default_rng(1 + rank)
+        wit = {i: int(v) for i, v in enumerate(rng.integers(0, 1 << 32, size=16 * nb))}
+        wit.update({16 * nb + i: v for i, v in enumerate([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19])})
+        blob, wires = cb.build(wit)
+        pis = ()
+        d = int(blob[:256].view(np.uint32)[2])
+        mix = f"sha256 x{nb} blocks (translated)"
+    else:
+        made = pkg.make_circuit(d, mix, seed=1 if sharded else 1 + rank, num_public_inputs=args.public_inputs)
+        blob, wires = made[0], made[1]
+        pis = made[2] if args.public_inputs else ()
     S = 1 if sharded else max(1, min(args.in_flight, args.steps))
     cds = [pkg.CircuitData(blob) for _ in range(S)]
     if args.mode == "sharded":
@@ -349,7 +375,9 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": f"synth(d={d},{mix}): {1 << d} gates -> 2^{d + 3} LDE rows, {W} wires / 80 routed, "
+                "workload": (f"synth(d={d},{mix})" if args.workload == "synth" else f"SHA-256 of a {args.sha_blocks}-block message: {args.sha_blocks} "
+                             f"chained Sha256Compression opcodes through the restated reference translator (translate.py)") +
+                            f": {1 << d} gates -> 2^{d + 3} LDE rows, {W} wires / 80 routed, "
                             f"KeccakGoldilocksConfig, rate 8, cap 2^4, 28 queries, 16 PoW bits (BASELINE configs[2] shape)",
                 "degree_bits": d, "lde_rows": 1 << (d + 3), "mix": mix, "public_inputs": args.public_inputs,
                 "parallelism": (f"one proof coset-sharded over {world} GPUs (8/{world} LDE cosets each; RCCL all-gather of caps, "
@@ -390,7 +418,7 @@ def main():
             "device": pkg.device_info()["name"],
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, d, mix, args.public_inputs, args.cpu_single_thread_bits)
+            out["cpu_baseline"] = cpu_baseline(pkg, d, mix if args.workload == "synth" else "sha", args.public_inputs, args.cpu_single_thread_bits)
         print(json.dumps(out), flush=True)
     for c_ in cds:
         c_.close()

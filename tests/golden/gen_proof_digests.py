@@ -27,6 +27,22 @@ CASES = [(5, "arith", 1, 0), (6, "sha", 2, 0), (7, "ecdsa", 3, 0), (9, "ecdsa", 
 LARGE = [(17, "sha", 1, 0), (17, "ecdsa", 1, 0), (17, "sha", 3, 4), (19, "ecdsa", 2, 0)]
 # hand-written ACIR-equivalents (BASELINE configs[0]: the fibonacci example program)
 HAND = {"fibonacci": mini_builder.fibonacci, "quadratic_example": mini_builder.quadratic_example}
+SHA256_IV = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+
+
+def sha256_compression_circuit(pkg, block=None, state=None):
+    """BASELINE configs[2]'s named circuit: ONE Sha256Compression opcode through the package's restatement of the
+    reference's translator (acvm-backend-plonky2_amd/translate.py; sha256_translator.rs:61-273).  Default
+    input = the reference's own test vector (circuit_translation/tests/test_sha256_internal.rs:481-549): the
+    padded empty message under the SHA-256 IV.  Returns (blob, wires, the 8 output words the circuit forces)."""
+    cb = pkg.translate.CircuitBuilderFromAcirToPlonky2()
+    cb.translate_circuit([("sha256_compression", list(range(16)), list(range(16, 24)), list(range(24, 32)))])
+    block = [1 << 31] + [0] * 15 if block is None else block
+    state = SHA256_IV if state is None else state
+    wit = {i: v for i, v in enumerate(block)}
+    wit.update({16 + i: v for i, v in enumerate(state)})
+    blob, wires = cb.build(wit)
+    return blob, wires, [cb.witness_value(24 + i) for i in range(8)]
 
 
 def record(oc, blob, wires, pis, meta):
@@ -74,6 +90,8 @@ def main():
     for name, fn in HAND.items():
         blob, wires = fn()
         hand.append(record(orc.OracleCircuit(blob), blob, wires, (), {"name": name}))
+    blob, wires, out = sha256_compression_circuit(pkg)
+    hand.append(record(orc.OracleCircuit(blob), blob, wires, (), {"name": "sha256_compression", "outputs": out}))
     with open(os.path.join(gold, "proof_digests_hand.json"), "w") as f:
         json.dump(hand, f, indent=1)
 

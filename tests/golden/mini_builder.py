@@ -160,10 +160,13 @@ class MiniBuilder:
         used = pi_row + 1 + const_rows
         d = max(2, (used - 1).bit_length())
         n = 1 << d
-        gates = [(G_NOOP, 0, 0, 0, 0), (G_CONSTANT, 2, 2, 1, 2), (G_PUBLIC_INPUT, 0, 4, 1, 0), (G_ARITHMETIC, NUM_OPS, NUM_OPS, 3, 2)]
+        # build() pads with NoopGates only when the row count is not a power of two already
+        gates = ([(G_NOOP, 0, 0, 0, 0)] if used < n else []) + [(G_CONSTANT, 2, 2, 1, 2), (G_PUBLIC_INPUT, 0, 4, 1, 0),
+                                                               (G_ARITHMETIC, NUM_OPS, NUM_OPS, 3, 2)]
+        o = len(gates) - 3
         NC = 3
         constants = np.zeros((NC, n), dtype=np.uint64)
-        row_gate = [3] * n_arith + [2] + [1] * const_rows + [0] * (n - used)
+        row_gate = [o + 2] * n_arith + [o + 1] + [o] * const_rows + [0] * (n - used)
         constants[0, :] = row_gate
         for r, (c0, c1) in enumerate(row_consts):
             constants[1, r], constants[2, r] = c0, c1

@@ -19,7 +19,7 @@ Mirrors, with the reference's names:
 What it is NOT: an ACIR *reader*.  The reference deserialises gzip + bincode `Program` bytes through the acvm
 crate (noir_and_plonky2_serialization.rs:42-64); no compiled program exists in the tree to test a reader on, so
 programs are given as Python data: [("assert_zero", mul_terms, linear, q_c), ("sha256_compression", inputs16,
-hash8, outputs8)].  Public parameters (which add PoseidonGate rows in `build()`) are not supported here.
+hash8, outputs8), ("range", w, num_bits), ("and" | "xor", lhs, rhs, output, num_bits)] (mod.rs:131-155).  Public parameters (which add PoseidonGate rows in `build()`) are not supported here.
 
 Host-side Python by design: translation runs once per circuit, off the hot path (north_star keeps this layer in
 Rust; this file exists so that the named SHA256 circuit can be built and proved without it).
@@ -472,6 +472,20 @@ class CircuitBuilderFromAcirToPlonky2:
         for ow, x0, x1 in zip(outputs, h0, (a, bb, c, d, e, f, g, h)):
             self.witness_target_map[ow] = self.convert_binary_number_to_number(B.add_module_32_bits(x0, x1, b))
 
+    # mod.rs:131-139: BlackBoxFuncCall::RANGE -> builder.range_check = split_le
+    def translate_range(self, w, num_bits):
+        assert num_bits <= 33, "Range checks with more than 33 bits are not allowed yet while using Plonky2 prover"
+        self.builder.split_le(self._target(w), num_bits)
+
+    # mod.rs:140-155, 222-238: AND / XOR through the bit decompositions
+    def translate_bitwise(self, lhs, rhs, output, num_bits, xor):
+        x = self.binary_number_target_for_witness(lhs, num_bits)
+        y = self.binary_number_target_for_witness(rhs, num_bits)
+        b = self.builder
+        bits = ([BinaryDigitsTarget.bit_xor(p, q, b) for p, q in zip(x.bits, y.bits)] if xor
+                else [b.and_(p, q) for p, q in zip(x.bits, y.bits)])
+        self.witness_target_map[output] = self.convert_binary_number_to_number(BinaryDigitsTarget(bits))
+
     def translate_circuit(self, opcodes, public_parameters=()):
         if public_parameters:
             raise NotImplementedError("public parameters (PoseidonGate rows of build()) are not restated here")
@@ -480,6 +494,10 @@ class CircuitBuilderFromAcirToPlonky2:
                 self.translate_assert_zero(*op[1:])
             elif op[0] == "sha256_compression":
                 self.translate_sha256_compression(*op[1:])
+            elif op[0] == "range":
+                self.translate_range(*op[1:])
+            elif op[0] in ("and", "xor"):
+                self.translate_bitwise(*op[1:], xor=op[0] == "xor")
             else:
                 raise NotImplementedError(op[0])
 

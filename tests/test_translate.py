@@ -120,3 +120,23 @@ def test_gpu_proves_the_sha256_circuit(pkg, sha_circuit):
     assert hashlib.sha256(proof.to_bytes()).hexdigest() == g["proof_sha256"]
     cd.verify(proof)
     cd.close()
+
+
+def test_range_and_xor_opcodes(pkg, orc):
+    """BlackBoxFuncCall::RANGE / AND / XOR (circuit_translation/mod.rs:131-155, 222-238), the way the reference's
+    test_blackbox.rs exercises them: right values prove and verify, an out-of-range witness is refused."""
+    tr = pkg.translate
+    cb = tr.CircuitBuilderFromAcirToPlonky2()
+    cb.translate_circuit([("range", 0, 8), ("range", 1, 33), ("and", 0, 2, 3, 8), ("xor", 0, 2, 4, 32),
+                          ("assert_zero", [], [(1, 3), (1, 4), (P - 1, 5)], 0)])
+    a, c = 0xB7, 0x5D
+    blob, wires = cb.build({0: a, 1: (1 << 33) - 1, 2: c, 5: (a & c) + (a ^ c)})   # the ACVM solver hands over every witness
+    assert cb.witness_value(3) == a & c and cb.witness_value(4) == a ^ c and cb.witness_value(5) == (a & c) + (a ^ c)
+    oc = orc.OracleCircuit(blob)
+    proof, _ = oc.prove(wires)
+    assert oc.verify(proof)
+    for bad in ({0: 256, 1: 5, 2: c}, {0: a, 1: 1 << 33, 2: c}):          # 256 is not 8 bits, 2^33 not 33 bits
+        cb2 = tr.CircuitBuilderFromAcirToPlonky2()
+        cb2.translate_circuit([("range", 0, 8), ("range", 1, 33), ("and", 0, 2, 3, 8)])
+        with pytest.raises(ValueError):
+            cb2.build(bad)

@@ -19,7 +19,62 @@ void set_err(const char *fmt, ...);
 std::string last_error_copy();
 void last_error_restore(const std::string &s);
 
-// ---- host transcript (iop/challenger.rs, Challenger<F, KeccakHash<25>>) ----
+// ---- the circuit's hasher on the host ------------------------------------------------------------
+// 0 = KeccakHash<25> (KeccakGoldilocksConfig, the reference: plonky2-backend/src/lib.rs:13): 25-byte digests,
+//     Keccak "hash onion" sponge permutation;
+// 1 = PoseidonHash (PoseidonGoldilocksConfig, the north_star's "Poseidon-GL Merkle-tree hashing"): digests are 4
+//     field elements (32 bytes), leaves are absorbed 8 elements per Poseidon permutation (overwrite mode,
+//     hash/hashing.rs hash_n_to_m_no_pad), nodes are compress(l, r) = permute(l || r || 0^4)[0..4], the
+//     challenger permutes with Poseidon.
+// Every C-ABI entry point selects the hasher of the handle it was given for the calling thread (use_hasher).
+struct HostHasher {
+  int kind = 0;
+  const gl_t *prc = nullptr;  // the 360 Poseidon round constants of the handle
+};
+extern thread_local HostHasher g_hh;
+inline size_t hh_bytes() { return g_hh.kind ? 32 : 25; }
+inline void sponge_permute(gl_t st[12]) {
+  if (g_hh.kind) poseidon_permute_host(st, g_hh.prc);
+  else keccak_permutation12(st);
+}
+inline void digest_elems(const dig_t &d, gl_t e[4]) {
+  if (g_hh.kind) for (int i = 0; i < 4; i++) e[i] = d.w[i];
+  else dig_to_elems(d, e);
+}
+inline bool dig_eq(const dig_t &a, const dig_t &b) {
+  return a.w[0] == b.w[0] && a.w[1] == b.w[1] && a.w[2] == b.w[2] && (g_hh.kind ? a.w[3] == b.w[3] : (a.w[3] & 0xFF) == (b.w[3] & 0xFF));
+}
+// H::hash_or_noop of a leaf of field elements
+inline dig_t leaf_digest(const gl_t *v, size_t n) {
+  dig_t d;
+  memset(&d, 0, sizeof d);
+  if (g_hh.kind) {
+    if (n <= 4) {
+      for (size_t i = 0; i < n; i++) d.w[i] = v[i];
+    } else {
+      poseidon_hash_no_pad_host(v, n, d.w, g_hh.prc);
+    }
+    return d;
+  }
+  if (n * 8 <= 25) {
+    for (size_t i = 0; i < n; i++) d.w[i] = v[i];
+    return d;
+  }
+  uint64_t h[4];
+  keccak256_words(v, n, h);
+  return dig_from_state(h);
+}
+// H::two_to_one
+inline dig_t node_digest(const dig_t &l, const dig_t &r) {
+  if (!g_hh.kind) return keccak_two_to_one(l, r);
+  gl_t st[12] = {l.w[0], l.w[1], l.w[2], l.w[3], r.w[0], r.w[1], r.w[2], r.w[3], 0, 0, 0, 0};
+  poseidon_permute_host(st, g_hh.prc);
+  dig_t d;
+  for (int i = 0; i < 4; i++) d.w[i] = st[i];
+  return d;
+}
+
+// ---- host transcript (iop/challenger.rs, Challenger<F, H>) ----
 struct Challenger {
   gl_t state[12];
   gl_t in[8];
@@ -30,7 +85,7 @@ struct Challenger {
   void duplex() {
     for (int i = 0; i < n_in; i++) state[i] = in[i];
     n_in = 0;
-    keccak_permutation12(state);
+    sponge_permute(state);
     for (int i = 0; i < 8; i++) out[i] = state[i];
     n_out = 8;
   }
@@ -41,7 +96,7 @@ struct Challenger {
   }
   void observe_digest(const dig_t &d) {
     gl_t e[4];
-    dig_to_elems(d, e);
+    digest_elems(d, e);
     for (int i = 0; i < 4; i++) observe(e[i]);
   }
   void observe_cap(const std::vector<dig_t> &cap) {
@@ -63,6 +118,11 @@ struct Challenger {
 };
 
 inline dig_t host_hash_no_pad(const std::vector<gl_t> &v) {
+  if (g_hh.kind) {
+    dig_t d;
+    poseidon_hash_no_pad_host(v.data(), v.size(), d.w, g_hh.prc);
+    return d;
+  }
   uint64_t h[4];
   keccak256_words(v.data(), v.size(), h);
   return dig_from_state(h);
@@ -138,6 +198,7 @@ struct CircuitState {
   // parameters
   uint32_t d, W, R, NC, num_selectors, K, QF, rate_bits, cap_h, pow_bits, num_queries, n_steps, arity[8];
   uint32_t num_gates, num_pi, flags, PP, nchunks;
+  uint32_t hasher = 0;  // 0 KeccakHash<25>, 1 PoseidonHash
   size_t n, N;
   uint32_t C;  // cosets = 2^rate_bits
   std::vector<GateDesc> gates;
@@ -205,6 +266,7 @@ struct p2gpu_circuit : p2::CircuitState {};
 
 namespace p2 {
 extern void (*g_circuit_release)(p2gpu_circuit *);  // hostcore.hip; set by prover.hip
+void use_hasher(const p2gpu_circuit *c);  // select the handle's hasher for this thread (hostcore.hip)
 void shard_assemble_cap(int world, unsigned rate_bits, size_t cap_per, const dig_t *gathered, std::vector<dig_t> &cap);
 // blob header + gate table + (optional) cap + k_is -> the host-side fields of the handle; leaves
 // *off at the constants table.  Used by p2gpu_circuit_create and p2gpu_verifier_create.

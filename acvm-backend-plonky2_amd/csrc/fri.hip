@@ -181,8 +181,9 @@ void fri_fold(hipStream_t st, const gl_t *in, uint32_t d, uint32_t ab, ext_t bet
 struct PowState {
   gl_t s[12];
 };
+template <int H>
 __global__ __launch_bounds__(256) void pow_kernel(PowState st0, uint32_t pos, uint32_t pow_bits, uint64_t base,
-                                                  uint64_t count, unsigned long long *result) {
+                                                  uint64_t count, unsigned long long *result, const gl_t *__restrict__ prc) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const uint64_t w = base + i;
@@ -192,17 +193,32 @@ __global__ __launch_bounds__(256) void pow_kernel(PowState st0, uint32_t pos, ui
 #pragma unroll
   for (int j = 0; j < 12; j++)
     if ((uint32_t)j == pos) st[j] = w;
-  keccak_permutation12(st);
+  if constexpr (H == 1) {  // Challenger<F, PoseidonHash>: the sponge permutation is Poseidon
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) {
+#pragma unroll
+      for (int j = 0; j < 12; j++) st[j] = gl_add(st[j], prc[12 * r + j]);
+      if (r < 4 || r >= 26) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) st[j] = poseidon_sbox(st[j]);
+      } else {
+        st[0] = poseidon_sbox(st[0]);
+      }
+      poseidon_mds(st);
+    }
+  } else {
+    keccak_permutation12(st);
+  }
   const uint64_t resp = st[7];
   if (pow_bits == 0 || (resp >> (64 - pow_bits)) == 0) atomicMin(result, (unsigned long long)w);
 }
 void pow_search(hipStream_t st, const gl_t state[12], uint32_t pos, uint32_t pow_bits, uint64_t base, uint64_t count,
-                unsigned long long *result) {
+                unsigned long long *result, const gl_t *prc) {
   PowState s;
   for (int i = 0; i < 12; i++) s.s[i] = state[i];
   ProfScope ps("pow_kernel", 0.0);
-  hipLaunchKernelGGL(pow_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, s, pos, pow_bits, base, count,
-                     result);
+  if (prc) hipLaunchKernelGGL(pow_kernel<1>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, s, pos, pow_bits, base, count, result, prc);
+  else hipLaunchKernelGGL(pow_kernel<0>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, s, pos, pow_bits, base, count, result, prc);
 }
 
 __global__ void gather_kernel(const uint64_t *addr, uint32_t count, gl_t *out) {

@@ -25,6 +25,11 @@ void set_err(const char *fmt, ...) {
   va_end(ap);
   g_err = buf;
 }
+thread_local HostHasher g_hh;
+void use_hasher(const p2gpu_circuit *c) {
+  g_hh.kind = c && c->hasher == 1;
+  g_hh.prc = c ? c->poseidon_rc : nullptr;
+}
 std::string last_error_copy() { return g_err; }
 void last_error_restore(const std::string &s) { g_err = s; }
 // Merkle cap in plonky2 order from the all-gather of every rank's local subtree roots:
@@ -146,7 +151,8 @@ int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off
     set_err("%s", msg);
     return rc;
   };
-  if (hasher != 0) return fail(P2GPU_E_BLOB, "unsupported hasher (only KeccakHash<25>)");
+  if (hasher > 1) return fail(P2GPU_E_BLOB, "unsupported hasher (0 = KeccakHash<25>, 1 = PoseidonHash)");
+  c->hasher = hasher;
   if (c->d < 1 || c->d > 24 || c->K < 1 || c->K > 2 || c->rate_bits < 1 || c->rate_bits > 3 || c->cap_h < c->rate_bits ||
       c->cap_h > c->rate_bits + c->d || c->n_steps > 8 || c->R > MAX_ROUTED || c->QF == 0 || c->num_gates > MAX_GATES ||
       c->num_queries > 64 || c->W < c->R || (1u << c->rate_bits) != c->QF || c->pow_bits > 32 || c->W > 4096 ||
@@ -205,9 +211,10 @@ int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off
   off += 8 * (size_t)c->R;
   if (c->flags & 1) {
     memset(&c->circuit_digest, 0, sizeof(dig_t));
-    memcpy(c->circuit_digest.w, &h[32], 25);
+    memcpy(c->circuit_digest.w, &h[32], c->hasher ? 32 : 25);
   }
   poseidon_round_constants_host(c->poseidon_rc);
+  use_hasher(c);
   *off_out = off;
   return P2GPU_OK;
 }
@@ -376,9 +383,10 @@ size_t p2gpu_proof_size_bound(const p2gpu_circuit *c) {
   if (!c) return 0;
   const size_t ncap = (size_t)1 << c->cap_h;
   const size_t ncs = c->NC + c->R, nzp = c->K * (1 + c->PP), nq = c->K * c->QF;
-  size_t sz = 3 * ncap * 25 + 16 * (ncs + c->W + nzp + nq + c->K) + c->n_steps * ncap * 25;
-  size_t per_q = 8 * (ncs + c->W + nzp + nq) + 4 * (1 + 25 * (size_t)(c->d + c->rate_bits));
-  for (uint32_t s = 0; s < c->n_steps; s++) per_q += (16u << c->arity[s]) + 1 + 25 * (size_t)(c->d + c->rate_bits);
+  const size_t hb = c->hasher ? 32 : 25;
+  size_t sz = 3 * ncap * hb + 16 * (ncs + c->W + nzp + nq + c->K) + c->n_steps * ncap * hb;
+  size_t per_q = 8 * (ncs + c->W + nzp + nq) + 4 * (1 + hb * (size_t)(c->d + c->rate_bits));
+  for (uint32_t s = 0; s < c->n_steps; s++) per_q += (16u << c->arity[s]) + 1 + hb * (size_t)(c->d + c->rate_bits);
   size_t n_final = c->n;
   for (uint32_t s = 0; s < c->n_steps; s++) n_final >>= c->arity[s];
   sz += per_q * c->num_queries + 16 * n_final + 8 + 8 * c->num_pi + 64;
@@ -393,13 +401,15 @@ void p2gpu_circuit_destroy(p2gpu_circuit *c) {
 
 int p2gpu_circuit_cap(const p2gpu_circuit *c, uint8_t *out) {
   if (!c || !out) return P2GPU_E_ARG;
-  for (size_t i = 0; i < c->cs.cap.size(); i++) memcpy(out + 25 * i, c->cs.cap[i].w, 25);
+  const size_t hb = c->hasher ? 32 : 25;
+  for (size_t i = 0; i < c->cs.cap.size(); i++) memcpy(out + hb * i, c->cs.cap[i].w, hb);
   return P2GPU_OK;
 }
 int p2gpu_circuit_device(const p2gpu_circuit *c) { return c ? c->device : P2GPU_E_ARG; }
-int p2gpu_circuit_digest(const p2gpu_circuit *c, uint8_t out[25]) {
+int p2gpu_circuit_hash_bytes(const p2gpu_circuit *c) { return c ? (c->hasher ? 32 : 25) : P2GPU_E_ARG; }
+int p2gpu_circuit_digest(const p2gpu_circuit *c, uint8_t *out) {
   if (!c || !out) return P2GPU_E_ARG;
-  memcpy(out, c->circuit_digest.w, 25);
+  memcpy(out, c->circuit_digest.w, c->hasher ? 32 : 25);
   return P2GPU_OK;
 }
 

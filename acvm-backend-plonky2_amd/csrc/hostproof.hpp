@@ -37,7 +37,7 @@ struct Cursor {
   dig_t digest() {
     dig_t d;
     memset(&d, 0, sizeof d);
-    if (const uint8_t *q = take(25)) memcpy(d.w, q, 25);
+    if (const uint8_t *q = take(hh_bytes())) memcpy(d.w, q, hh_bytes());
     return d;
   }
   void digests(std::vector<dig_t> &v, size_t n) {
@@ -46,29 +46,12 @@ struct Cursor {
   }
 };
 
-inline bool dig_eq(const dig_t &a, const dig_t &b) {
-  return a.w[0] == b.w[0] && a.w[1] == b.w[1] && a.w[2] == b.w[2] && (a.w[3] & 0xFF) == (b.w[3] & 0xFF);
-}
-
-// KeccakHash<25>::hash_or_noop of a leaf of field elements
-inline dig_t leaf_digest(const gl_t *v, size_t n) {
-  if (n * 8 <= 25) {
-    dig_t d;
-    memset(&d, 0, sizeof d);
-    for (size_t i = 0; i < n; i++) d.w[i] = v[i];
-    return d;
-  }
-  uint64_t h[4];
-  keccak256_words(v, n, h);
-  return dig_from_state(h);
-}
-
 // hash/merkle_proofs.rs verify_merkle_proof_to_cap
 inline bool merkle_path_ok(const gl_t *leaf, size_t n, size_t index, const std::vector<dig_t> &siblings,
                     const std::vector<dig_t> &cap) {
   dig_t cur = leaf_digest(leaf, n);
   for (const dig_t &s : siblings) {
-    cur = (index & 1) ? keccak_two_to_one(s, cur) : keccak_two_to_one(cur, s);
+    cur = (index & 1) ? node_digest(s, cur) : node_digest(cur, s);
     index >>= 1;
   }
   return index < cap.size() && dig_eq(cur, cap[index]);

@@ -56,20 +56,21 @@ void bitrev_cols(hipStream_t st, const gl_t *in, gl_t *out, uint32_t d, uint32_t
 
 // ---- merkle.hip ----
 // leaf digests of an LDE batch: lde [cosets][cols][n] -> dig [cosets][n]
-void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig);
+// prc: the handle's Poseidon round constants in device memory selects PoseidonHash; nullptr = KeccakHash<25>
+void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig, const gl_t *prc = nullptr);
 // row-major rows (stage-level operator)
 void hash_rows(hipStream_t st, const gl_t *rows, size_t n_rows, uint32_t row_len, dig_t *dig);
 // FRI step leaves: vals [cosets][2][npc] (ext coordinates), leaf = 16 ext values; dig [cosets][npc/16]
 void hash_fri_leaves(hipStream_t st, const gl_t *vals, uint32_t lg_npc, uint32_t cosets, uint32_t arity_bits,
-                     dig_t *dig);
+                     dig_t *dig, const gl_t *prc = nullptr);
 // one tree level: in [cosets][m] -> out [cosets][m/2], out[c][k] = H(in[c][k], in[c][k + m/2])
 // incremental variant: absorb the rate blocks [blk0, blk0 + nblk) (17 columns each) into the sponge
 // states kept in `state` ([cosets][25][n]); `last` also absorbs the tail + padding and writes digests
 void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, uint32_t blk0,
                      uint32_t nblk, bool first, bool last, uint64_t *state, dig_t *dig);
-void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m);
+void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m, const gl_t *prc = nullptr);
 // every level below one with m <= 4096 nodes per coset, down to cap_per nodes per coset, in one launch
-void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per);
+void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc = nullptr);
 
 // ---- plonk.hip ----
 struct ZsArgs {
@@ -137,7 +138,7 @@ void fri_quotient_values(hipStream_t st, const gl_t *F0, const gl_t *F1, uint32_
 void fri_fold(hipStream_t st, const gl_t *in /*[2][n]*/, uint32_t d, uint32_t arity_bits, ext_t beta, gl_t *out);
 // proof of work: smallest w in [base, base + count) with leading zeros; result via atomicMin
 void pow_search(hipStream_t st, const gl_t state[12], uint32_t pos, uint32_t pow_bits, uint64_t base, uint64_t count,
-                unsigned long long *result);
+                unsigned long long *result, const gl_t *prc = nullptr);
 // gather: out[i] = *(const u64 *)addr[i] (absolute device addresses; address 0 -> value 0)
 void gather_u64(hipStream_t st, const uint64_t *addr, uint32_t count, gl_t *out);
 

@@ -17,6 +17,55 @@
 
 namespace p2 {
 
+// ---- PoseidonHash (hasher 1): Poseidon-Goldilocks, width 12, 8 full + 22 partial rounds, x^7 -----------------
+// plonky2 0.2.2 hash/poseidon.rs in its plain form (constants added, S-box, MDS per round); the round
+// constants come from the handle's table in global memory (360 words, L1/L2 resident).  One lane owns one
+// sponge, like the Keccak path; rounds are not unrolled (the 12-word state, its MDS temporaries and the S-box
+// products already need ~70 VGPRs).
+__device__ __forceinline__ void poseidon_permute_dev(gl_t st[12], const gl_t *__restrict__ prc) {
+#pragma unroll 1
+  for (int r = 0; r < 30; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], prc[12 * r + i]);
+    if (r < 4 || r >= 26) {
+#pragma unroll
+      for (int i = 0; i < 12; i++) st[i] = poseidon_sbox(st[i]);
+    } else {
+      st[0] = poseidon_sbox(st[0]);
+    }
+    poseidon_mds(st);
+  }
+}
+// hash_n_to_m_no_pad: overwrite-mode sponge, 8 elements per permutation, first 4 words out
+template <class F>
+__device__ __forceinline__ dig_t poseidon_sponge(uint32_t nwords, F get, const gl_t *prc) {
+  gl_t st[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) st[i] = 0;
+  for (uint32_t off = 0; off < nwords; off += 8) {
+#pragma unroll
+    for (int w = 0; w < 8; w++)
+      if (off + w < nwords) st[w] = get(off + w);
+    poseidon_permute_dev(st, prc);
+  }
+  dig_t d;
+  d.w[0] = st[0]; d.w[1] = st[1]; d.w[2] = st[2]; d.w[3] = st[3];
+  return d;
+}
+// hash/hashing.rs compress
+__device__ __forceinline__ dig_t poseidon_two_to_one(const dig_t &l, const dig_t &r, const gl_t *prc) {
+  gl_t st[12] = {l.w[0], l.w[1], l.w[2], l.w[3], r.w[0], r.w[1], r.w[2], r.w[3], 0, 0, 0, 0};
+  poseidon_permute_dev(st, prc);
+  dig_t d;
+  d.w[0] = st[0]; d.w[1] = st[1]; d.w[2] = st[2]; d.w[3] = st[3];
+  return d;
+}
+template <int H>
+__device__ __forceinline__ dig_t node_hash(const dig_t &l, const dig_t &r, const gl_t *prc) {
+  if constexpr (H == 1) return poseidon_two_to_one(l, r, prc);
+  else return keccak_two_to_one(l, r);
+}
+
 template <class F>
 __device__ __forceinline__ dig_t sponge_hash(uint32_t nwords, F get) {
   uint64_t st[25];
@@ -52,9 +101,20 @@ __device__ __forceinline__ dig_t sponge_hash(uint32_t nwords, F get) {
   return dig_from_state(st);
 }
 
-// hash_or_noop: rows of <= 3 elements are copied, not hashed
-template <class F>
-__device__ __forceinline__ dig_t hash_or_noop(uint32_t nwords, F get) {
+// hash_or_noop: rows of <= 3 elements (Keccak: 25 bytes) / <= 4 elements (Poseidon: a HashOut) are copied
+template <int H = 0, class F>
+__device__ __forceinline__ dig_t hash_or_noop(uint32_t nwords, F get, const gl_t *prc = nullptr) {
+  if constexpr (H == 1) {
+    if (nwords <= 4) {
+      dig_t d;
+      d.w[0] = nwords > 0 ? get(0) : 0;
+      d.w[1] = nwords > 1 ? get(1) : 0;
+      d.w[2] = nwords > 2 ? get(2) : 0;
+      d.w[3] = nwords > 3 ? get(3) : 0;
+      return d;
+    }
+    return poseidon_sponge(nwords, get, prc);
+  }
   if (nwords * 8 <= 25) {
     dig_t d;
     d.w[0] = nwords > 0 ? get(0) : 0;
@@ -66,14 +126,15 @@ __device__ __forceinline__ dig_t hash_or_noop(uint32_t nwords, F get) {
   return sponge_hash(nwords, get);
 }
 
+template <int H>
 __global__ __launch_bounds__(256) void hash_lde_leaves_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
-                                                              dig_t *__restrict__ dig) {
+                                                              dig_t *__restrict__ dig, const gl_t *__restrict__ prc) {
   const size_t n = (size_t)1 << d;
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t c = blockIdx.y;
   if (k >= n) return;
   const gl_t *base = lde + (size_t)c * cols * n + k;
-  dig[(size_t)c * n + k] = hash_or_noop(cols, [&](uint32_t i) { return base[(size_t)i * n]; });
+  dig[(size_t)c * n + k] = hash_or_noop<H>(cols, [&](uint32_t i) { return base[(size_t)i * n]; }, prc);
 }
 
 // Leaf hashing for a witness that arrives in column chunks (p2gpu_prove): a Keccak sponge absorbs
@@ -125,35 +186,39 @@ __global__ __launch_bounds__(256) void hash_rows_kernel(const gl_t *__restrict__
 }
 
 // leaf (r, kl): ext values at k = bitrev_ab(t) * (npc >> ab) + kl, t < 2^ab, flattened (c0, c1)
+template <int H>
 __global__ __launch_bounds__(256) void hash_fri_leaves_kernel(const gl_t *__restrict__ vals, uint32_t lg_npc,
-                                                              uint32_t ab, dig_t *__restrict__ dig) {
+                                                              uint32_t ab, dig_t *__restrict__ dig, const gl_t *__restrict__ prc) {
   const uint32_t npc = 1u << lg_npc, per = npc >> ab;
   const uint32_t kl = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = blockIdx.y;
   if (kl >= per) return;
   const gl_t *c0 = vals + (size_t)r * 2 * npc, *c1 = c0 + npc;
-  dig[(size_t)r * per + kl] = hash_or_noop(2u << ab, [&](uint32_t w) {
+  dig[(size_t)r * per + kl] = hash_or_noop<H>(2u << ab, [&](uint32_t w) {
     uint32_t t = w >> 1;
     uint32_t k = bitrev32(t, ab) * per + kl;
     return (w & 1) ? c1[k] : c0[k];
-  });
+  }, prc);
 }
 
+template <int H>
 __global__ __launch_bounds__(256) void merkle_level_kernel(const dig_t *__restrict__ in, dig_t *__restrict__ out,
-                                                           uint32_t m) {
+                                                           uint32_t m, const gl_t *__restrict__ prc) {
   const uint32_t half = m >> 1;
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t c = blockIdx.y;
   if (k >= half) return;
   const dig_t l = in[(size_t)c * m + k], r = in[(size_t)c * m + k + half];
-  out[(size_t)c * half + k] = keccak_two_to_one(l, r);
+  out[(size_t)c * half + k] = node_hash<H>(l, r, prc);
 }
 
 // All remaining levels of a tree in ONE launch once a level has <= 4096 nodes per coset: one
 // 1024-thread block per coset walks the levels (each level is one Keccak-f of dependent
 // latency; separate launches would add a boundary per level).  Levels are laid out back to
 // back: level with m nodes per coset at `lvl`, the next one at lvl + cosets * m.
-__global__ __launch_bounds__(1024) void merkle_tail_kernel(dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per) {
+template <int H>
+__global__ __launch_bounds__(1024) void merkle_tail_kernel(dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per,
+                                                           const gl_t *__restrict__ prc) {
   const uint32_t c = blockIdx.x;
   while (m > cap_per) {
     const uint32_t half = m >> 1;
@@ -161,26 +226,27 @@ __global__ __launch_bounds__(1024) void merkle_tail_kernel(dig_t *lvl, uint32_t 
     dig_t *out = lvl + (size_t)cosets * m + (size_t)c * half;
     for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
       const dig_t l = in[k], r = in[k + half];
-      out[k] = keccak_two_to_one(l, r);
+      out[k] = node_hash<H>(l, r, prc);
     }
     __syncthreads();
     lvl += (size_t)cosets * m;
     m = half;
   }
 }
-void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per) {
+void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc) {
   if (m <= cap_per) return;
   ProfScope ps("merkle_tail_kernel", 96.0 * cosets * (double)(m - cap_per));
   uint32_t threads = m / 2 >= 1024 ? 1024 : (m / 2 >= 64 ? m / 2 : 64);
-  hipLaunchKernelGGL(merkle_tail_kernel, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per);
+  if (prc) hipLaunchKernelGGL(merkle_tail_kernel<1>, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per, prc);
+  else hipLaunchKernelGGL(merkle_tail_kernel<0>, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per, prc);
 }
 
-void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig) {
+void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig, const gl_t *prc) {
   size_t n = (size_t)1 << d;
   uint32_t threads = n >= 256 ? 256 : 64;
   ProfScope ps("hash_lde_leaves_kernel", (8.0 * cols + 32.0) * cosets * (double)n);
-  hipLaunchKernelGGL(hash_lde_leaves_kernel, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols,
-                     d, dig);
+  if (prc) hipLaunchKernelGGL(hash_lde_leaves_kernel<1>, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc);
+  else hipLaunchKernelGGL(hash_lde_leaves_kernel<0>, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc);
 }
 void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, uint32_t blk0,
                      uint32_t nblk, bool first, bool last, uint64_t *state, dig_t *dig) {
@@ -194,19 +260,19 @@ void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d,
 void hash_rows(hipStream_t st, const gl_t *rows, size_t n_rows, uint32_t row_len, dig_t *dig) {
   hipLaunchKernelGGL(hash_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, st, rows, n_rows, row_len, dig);
 }
-void hash_fri_leaves(hipStream_t st, const gl_t *vals, uint32_t lg_npc, uint32_t cosets, uint32_t ab, dig_t *dig) {
+void hash_fri_leaves(hipStream_t st, const gl_t *vals, uint32_t lg_npc, uint32_t cosets, uint32_t ab, dig_t *dig, const gl_t *prc) {
   uint32_t per = (1u << lg_npc) >> ab;
   uint32_t threads = per >= 256 ? 256 : 64;
   ProfScope ps("hash_fri_leaves_kernel", (16.0 * (1u << ab) + 32.0) * cosets * (double)per);
-  hipLaunchKernelGGL(hash_fri_leaves_kernel, dim3((per + threads - 1) / threads, cosets), dim3(threads), 0, st, vals,
-                     lg_npc, ab, dig);
+  if (prc) hipLaunchKernelGGL(hash_fri_leaves_kernel<1>, dim3((per + threads - 1) / threads, cosets), dim3(threads), 0, st, vals, lg_npc, ab, dig, prc);
+  else hipLaunchKernelGGL(hash_fri_leaves_kernel<0>, dim3((per + threads - 1) / threads, cosets), dim3(threads), 0, st, vals, lg_npc, ab, dig, prc);
 }
-void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m) {
+void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m, const gl_t *prc) {
   uint32_t half = m >> 1;
   uint32_t threads = half >= 256 ? 256 : 64;
   ProfScope ps("merkle_level_kernel", 96.0 * cosets * (double)half);
-  hipLaunchKernelGGL(merkle_level_kernel, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out,
-                     m);
+  if (prc) hipLaunchKernelGGL(merkle_level_kernel<1>, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out, m, prc);
+  else hipLaunchKernelGGL(merkle_level_kernel<0>, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out, m, prc);
 }
 
 }  // namespace p2

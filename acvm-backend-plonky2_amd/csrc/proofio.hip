@@ -79,7 +79,7 @@ struct Out {
   void u32(uint32_t x) { put(&x, 4); }
   void u64(uint64_t x) { put(&x, 8); }
   void ext(ext_t e) { u64(e.c0); u64(e.c1); }
-  void dig(const dig_t &d) { put(d.w, 25); }
+  void dig(const dig_t &d) { put(d.w, hh_bytes()); }
   void path(const std::vector<dig_t> &p) {
     u8((uint8_t)p.size());
     for (auto &d : p) dig(d);
@@ -242,7 +242,7 @@ bool decompress_paths(unsigned height_total, unsigned cap_h, const std::vector<s
         it = seen.emplace(node ^ 1, (*cpaths[q])[used[q]++]).first;
       }
       const dig_t &cur = seen[node], &sib = it->second;
-      seen[node >> 1] = (node & 1) ? keccak_two_to_one(sib, cur) : keccak_two_to_one(cur, sib);
+      seen[node >> 1] = (node & 1) ? node_digest(sib, cur) : node_digest(cur, sib);
     }
   // duplicate queries share one stored path: only the first copy must be used up
   std::set<size_t> first;
@@ -483,6 +483,7 @@ int emit(const Out &o, uint8_t *out, size_t *out_len) {
 extern "C" {
 
 int p2gpu_proof_compress(const p2gpu_circuit *c, const uint8_t *proof, size_t len, uint8_t *out, size_t *out_len) try {
+  use_hasher(c);
   if (!c || !proof || !out_len) return P2GPU_E_ARG;
   ProofData P;
   if (int rc = parse_uncompressed(c, proof, len, P)) return rc;
@@ -492,6 +493,7 @@ int p2gpu_proof_compress(const p2gpu_circuit *c, const uint8_t *proof, size_t le
 } P2GPU_CATCH
 
 int p2gpu_proof_decompress(const p2gpu_circuit *c, const uint8_t *cproof, size_t len, uint8_t *out, size_t *out_len) try {
+  use_hasher(c);
   if (!c || !cproof || !out_len) return P2GPU_E_ARG;
   ProofData P;
   if (int rc = do_decompress(c, cproof, len, P)) return rc;
@@ -501,6 +503,7 @@ int p2gpu_proof_decompress(const p2gpu_circuit *c, const uint8_t *cproof, size_t
 } P2GPU_CATCH
 
 int p2gpu_verify_compressed(const p2gpu_circuit *c, const uint8_t *cproof, size_t len) try {
+  use_hasher(c);
   if (!c || !cproof) return P2GPU_E_ARG;
   ProofData P;
   if (int rc = do_decompress(c, cproof, len, P)) return rc;

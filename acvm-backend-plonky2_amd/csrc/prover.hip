@@ -250,17 +250,20 @@ size_t tail_nodes() {
   return v;
 }
 
+// device copy of the Poseidon round constants when the circuit's hasher is PoseidonHash, nullptr for Keccak
+const gl_t *hprc(const p2gpu_circuit *c) { return c->hasher == 1 ? c->d_prc.p : nullptr; }
+
 int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
   const uint32_t C = c->C, CL = b.ncl;
   size_t m = m0;
   const size_t cap_target = ((size_t)1 << c->cap_h) >> c->rate_bits;
   for (size_t l = 1; l < b.level_off.size(); l++) {
     if (m <= tail_nodes()) {  // the rest of the tree in one launch
-      merkle_tail(c->stream, b.dig.p + b.level_off[l - 1], CL, (uint32_t)m, (uint32_t)cap_target);
+      merkle_tail(c->stream, b.dig.p + b.level_off[l - 1], CL, (uint32_t)m, (uint32_t)cap_target, hprc(c));
       m = cap_target;
       break;
     }
-    merkle_level(c->stream, b.dig.p + b.level_off[l - 1], b.dig.p + b.level_off[l], CL, (uint32_t)m);
+    merkle_level(c->stream, b.dig.p + b.level_off[l - 1], b.dig.p + b.level_off[l], CL, (uint32_t)m, hprc(c));
     m >>= 1;
   }
   const size_t cap_per = m;
@@ -296,14 +299,14 @@ int batch_commit_from_coeffs(p2gpu_circuit *c, Batch &b) {
     ntt_batch(c->stream, c->plan_fwd, b.coeffs.p, b.lde.p, b.cols, b.ncl, c->scale.p, 1, false, b.cm);
   }
   {
-    hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p);
+    hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p, hprc(c));
   }
   TRACE(c, "  lde + leaf hash");
   return tree_build(c, b, c->n);
 }
 // hash + tree of a batch whose LDE is already in place
 int batch_commit_from_lde(p2gpu_circuit *c, Batch &b) {
-  hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p);
+  hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p, hprc(c));
   TRACE(c, "  leaf hash");
   return tree_build(c, b, c->n);
 }
@@ -338,7 +341,7 @@ struct Buf {
     u64(e.c0);
     u64(e.c1);
   }
-  void dig(const dig_t &d) { put(d.w, 25); }
+  void dig(const dig_t &d) { put(d.w, hh_bytes()); }
 };
 
 // sibling positions (within the digest buffer of a tree) for leaf index `j`
@@ -390,6 +393,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   poseidon_hash_no_pad_host(pis, n_pi, pih, c->poseidon_rc);
 
   c->pin.reset();
+  use_hasher(c);
   // ---- 1. wires commitment ----
   g_hp.mark("start");
   TRACE(c, "enter");
@@ -595,7 +599,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     const uint32_t ab = c->arity[s];
     Batch &tr = c->fri_trees[s];
     {
-      hash_fri_leaves(st, c->fri_vals[s].p, ds, tr.ncl, ab, tr.dig.p);
+      hash_fri_leaves(st, c->fri_vals[s].p, ds, tr.ncl, ab, tr.dig.p, hprc(c));
     }
     if (int rc = tree_build(c, tr, ((size_t)1 << ds) >> ab)) return rc;
     ch.observe_cap(tr.cap);
@@ -645,7 +649,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
       const uint64_t W_ = split ? (uint64_t)c->shard_world : 1, per = (batch + W_ - 1) / W_;
       const uint64_t my0 = base + per * (uint64_t)(split ? c->shard_rank : 0);
       const uint64_t myn = my0 >= base + batch ? 0 : std::min(per, base + batch - my0);
-      if (myn) pow_search(st, inter, (uint32_t)ch.n_in, c->pow_bits, my0, myn, c->pow_result.p);
+      if (myn) pow_search(st, inter, (uint32_t)ch.n_in, c->pow_bits, my0, myn, c->pow_result.p, hprc(c));
       if (split) {
         if (int rc = shard_allgather(c, c->pow_result.p, c->xchg_recv.p, 8)) return rc;
         unsigned long long *allw = c->pin.take<unsigned long long>((size_t)c->shard_world);
@@ -1168,14 +1172,14 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   }
   if (cap_in) {
     for (size_t i = 0; i < c->cs.cap.size(); i++)
-      if (memcmp(cap_in + 32 * i, c->cs.cap[i].w, 25)) return fail(P2GPU_E_CAP_MISMATCH, "constants_sigmas cap mismatch");
+      if (memcmp(cap_in + 32 * i, c->cs.cap[i].w, c->hasher ? 32 : 25)) return fail(P2GPU_E_CAP_MISMATCH, "constants_sigmas cap mismatch");
   }
   if (!(c->flags & 1)) {
     // circuit_builder.rs build(): H::hash_no_pad(cap.flatten() || hash_pad([]).to_vec() || [degree_bits])  (pinned: tests/test_reference_proofs.py)
     std::vector<gl_t> parts;
     for (auto &dg : c->cs.cap) {
       gl_t e[4];
-      dig_to_elems(dg, e);
+      digest_elems(dg, e);
       parts.insert(parts.end(), e, e + 4);
     }
     std::vector<gl_t> pad(8, 0);  // hash_pad([]): pad10*1 to the sponge rate
@@ -1183,7 +1187,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     pad[7] = 1;
     dig_t ds = host_hash_no_pad(pad);
     gl_t e[4];
-    dig_to_elems(ds, e);
+    digest_elems(ds, e);
     parts.insert(parts.end(), e, e + 4);
     parts.push_back(d);
     c->circuit_digest = host_hash_no_pad(parts);
@@ -1361,7 +1365,8 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
   const size_t n = c->n;
   const gl_t ninv = gl_inv((gl_t)n);
   Batch &b = c->wires;
-  const bool incremental = W > chunk;  // (also implies a hashed leaf: more than 3 columns)
+  // (also implies a hashed leaf: more than 3 columns); the chunk-wise sponge is the Keccak one (17-column rate blocks)
+  const bool incremental = W > chunk && c->hasher == 0;
   if (incremental && c->hash_state.count < (size_t)b.ncl * 25 * n) {  // also after set_shard(world 1 again): more local cosets
     c->hash_state.release();
     HIP_TRY(c->hash_state.alloc((size_t)b.ncl * 25 * n));

@@ -120,7 +120,7 @@ int p2gpu_verifier_create(const uint8_t *blob, size_t len, p2gpu_circuit **out) 
   c->cs.cap.resize((size_t)1 << c->cap_h);
   for (size_t i = 0; i < c->cs.cap.size(); i++) {
     memset(&c->cs.cap[i], 0, sizeof(dig_t));
-    memcpy(c->cs.cap[i].w, cap_in + 32 * i, 25);
+    memcpy(c->cs.cap[i].w, cap_in + 32 * i, c->hasher ? 32 : 25);
   }
   c->device = -1;  // no device state: only p2gpu_verify and the getters accept this handle
   *out = c;
@@ -144,8 +144,8 @@ int p2gpu_circuit_export_vk(const p2gpu_circuit *c, uint8_t *out, size_t *len) t
   h[7] = c->K; h[8] = c->QF; h[9] = c->rate_bits; h[10] = c->cap_h; h[11] = c->pow_bits; h[12] = c->num_queries;
   h[13] = c->n_steps;
   for (int i = 0; i < 8; i++) h[14 + i] = c->arity[i];
-  h[22] = 0; h[23] = c->num_gates; h[24] = c->num_pi; h[25] = 3; h[26] = c->PP;
-  memcpy(&h[32], c->circuit_digest.w, 25);
+  h[22] = c->hasher; h[23] = c->num_gates; h[24] = c->num_pi; h[25] = 3; h[26] = c->PP;
+  memcpy(&h[32], c->circuit_digest.w, c->hasher ? 32 : 25);
   memcpy(out, h, sizeof h);
   size_t off = 256;
   for (const GateDesc &G : c->gates) {
@@ -160,7 +160,7 @@ int p2gpu_circuit_export_vk(const p2gpu_circuit *c, uint8_t *out, size_t *len) t
   }
   for (size_t i = 0; i < ncap; i++) {
     memset(out + off, 0, 32);
-    memcpy(out + off, c->cs.cap[i].w, 25);
+    memcpy(out + off, c->cs.cap[i].w, c->hasher ? 32 : 25);
     off += 32;
   }
   memcpy(out + off, c->k_is.data(), 8 * (size_t)c->R);
@@ -171,6 +171,7 @@ int p2gpu_circuit_export_vk(const p2gpu_circuit *c, uint8_t *out, size_t *len) t
 
 int p2gpu_verify(const p2gpu_circuit *c, const uint8_t *proof, size_t len) try {
   if (!c || !proof) return P2GPU_E_ARG;
+  use_hasher(c);
   const uint32_t K = c->K, R = c->R, W = c->W, NC = c->NC, QF = c->QF, PP = c->PP, d = c->d;
   const uint32_t ncs = NC + R, nzp = K * (1 + PP), nq = K * QF, nall = ncs + W + nzp + nq;
   const unsigned lgN = d + c->rate_bits;
@@ -193,7 +194,8 @@ int p2gpu_verify(const p2gpu_circuit *c, const uint8_t *proof, size_t len) try {
   if (!in.ok) return reject("truncated or non-canonical header (caps / openings)");
   const uint32_t oracle_cols[4] = {ncs, W, nzp, nq};
   size_t query_bytes = 0, final_len = c->n;
-  for (int o = 0; o < 4; o++) query_bytes += 8 * (size_t)oracle_cols[o] + 1 + 25 * (size_t)(lgN - c->cap_h);
+  const size_t hb = hh_bytes();
+  for (int o = 0; o < 4; o++) query_bytes += 8 * (size_t)oracle_cols[o] + 1 + hb * (size_t)(lgN - c->cap_h);
   {
     unsigned lg = lgN;
     for (uint32_t s = 0; s < c->n_steps; s++) {
@@ -201,7 +203,7 @@ int p2gpu_verify(const p2gpu_circuit *c, const uint8_t *proof, size_t len) try {
       if (ab < 1 || ab > MAX_ARITY_BITS || lg < ab + c->cap_h || (final_len >> ab) == 0) return reject("bad reduction arity in circuit");
       lg -= ab;
       final_len >>= ab;
-      query_bytes += ((size_t)16 << ab) + 1 + 25 * (size_t)(lg - c->cap_h);
+      query_bytes += ((size_t)16 << ab) + 1 + hb * (size_t)(lg - c->cap_h);
     }
   }
   const size_t queries_at = in.at;

@@ -85,6 +85,7 @@ def load_library():
     lib.p2gpu_proof_size_bound.argtypes = [vp]
     lib.p2gpu_proof_size_bound.restype = sz
     lib.p2gpu_circuit_device.argtypes = [vp]
+    lib.p2gpu_circuit_hash_bytes.argtypes = [vp]
     lib.p2gpu_prove.argtypes = [vp, vp, vp, ctypes.c_uint32, u8p, ctypes.POINTER(sz), ctypes.POINTER(_Timings)]
     lib.p2gpu_prove_dev.argtypes = lib.p2gpu_prove.argtypes
     lib.p2gpu_prove_routed.argtypes = lib.p2gpu_prove.argtypes
@@ -172,14 +173,18 @@ class CircuitData:
         return 1 << self.degree_bits
 
     def constants_sigmas_cap(self):
-        out = np.zeros(25 << self.cap_height, dtype=np.uint8)
+        out = np.zeros(self.hash_bytes() << self.cap_height, dtype=np.uint8)
         _check(self._lib.p2gpu_circuit_cap(self._h, out.ctypes.data))
         return out.tobytes()
 
     def circuit_digest(self):
-        out = np.zeros(25, dtype=np.uint8)
+        out = np.zeros(self.hash_bytes(), dtype=np.uint8)
         _check(self._lib.p2gpu_circuit_digest(self._h, out.ctypes.data))
         return out.tobytes()
+
+    def hash_bytes(self):
+        """Digest size of the circuit's hasher: 25 (KeccakHash<25>) or 32 (PoseidonHash)."""
+        return int(self._lib.p2gpu_circuit_hash_bytes(self._h))
 
     def device_index(self):
         """HIP device the handle's buffers and streams live on."""
@@ -391,13 +396,16 @@ class VerifierCircuitData(_ProofFormats):
     def to_bytes(self):
         return self._blob.tobytes()
 
+    def hash_bytes(self):
+        return int(self._lib.p2gpu_circuit_hash_bytes(self._h))
+
     def circuit_digest(self):
-        out = np.zeros(25, dtype=np.uint8)
+        out = np.zeros(self.hash_bytes(), dtype=np.uint8)
         _check(self._lib.p2gpu_circuit_digest(self._h, out.ctypes.data))
         return out.tobytes()
 
     def constants_sigmas_cap(self):
-        out = np.zeros(25 << self.cap_height, dtype=np.uint8)
+        out = np.zeros(self.hash_bytes() << self.cap_height, dtype=np.uint8)
         _check(self._lib.p2gpu_circuit_cap(self._h, out.ctypes.data))
         return out.tobytes()
 

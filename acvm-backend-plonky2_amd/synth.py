@@ -28,10 +28,12 @@ def _lib():
     return _LIB
 
 
-def make_circuit(degree_bits, mix="arith", seed=1, num_public_inputs=0, num_wires=234):
+def make_circuit(degree_bits, mix="arith", seed=1, num_public_inputs=0, num_wires=234, hasher=0):
     """Returns (blob: np.uint8[...], wires: np.uint64[num_wires][2^degree_bits]) and, when
     num_public_inputs > 0, additionally the public input values (np.uint64[num_public_inputs]).
-    num_wires: 234 (wide_ecc_config, the translator's shape) or 135 (standard_recursion_config)."""
+    num_wires: 234 (wide_ecc_config, the translator's shape) or 135 (standard_recursion_config).
+    hasher: 0 = KeccakHash<25> (the reference's KeccakGoldilocksConfig), 1 = PoseidonHash
+    (PoseidonGoldilocksConfig: Poseidon Merkle trees, challenger and circuit digest) -- header word 22."""
     lib = _lib()
     blob = ctypes.POINTER(ctypes.c_uint8)()
     blen = ctypes.c_size_t()
@@ -45,6 +47,7 @@ def make_circuit(degree_bits, mix="arith", seed=1, num_public_inputs=0, num_wire
         raise ValueError(f"p2synth_make({degree_bits}, {mix!r}) failed: {rc}")
     try:
         b = np.ctypeslib.as_array(blob, (blen.value,)).copy()
+        b[:256].view(np.uint32)[22] = hasher
         w = np.ctypeslib.as_array(wires, (nw.value, 1 << degree_bits)).copy()
     finally:
         lib.p2synth_free(blob)

@@ -165,6 +165,9 @@ def main():
                          "translator builds for --sha-blocks chained Sha256Compression opcodes (translate.py; 4 blocks = 2^17 gates "
                          "= 2^20 LDE rows; translating takes ~15 s per block in Python, outside every timed region)")
     ap.add_argument("--sha-blocks", type=int, default=4)
+    ap.add_argument("--hasher", choices=["keccak", "poseidon"], default="keccak",
+                    help="keccak = KeccakGoldilocksConfig (the reference, default); poseidon = PoseidonGoldilocksConfig "
+                         "(Poseidon Merkle trees / challenger / digest; synth workload only)")
     ap.add_argument("--public-inputs", type=int, default=0,
                     help="public inputs of the synthetic circuit (> 0 adds PoseidonGate rows to the circuit and the "
                          "PoseidonGate to the gate set every LDE row evaluates); 0 = the BASELINE parity shape")
@@ -240,7 +243,8 @@ def main():
         d = int(blob[:256].view(np.uint32)[2])
         mix = f"sha256 x{nb} blocks (translated)"
     else:
-        made = pkg.make_circuit(d, mix, seed=1 if sharded else 1 + rank, num_public_inputs=args.public_inputs)
+        made = pkg.make_circuit(d, mix, seed=1 if sharded else 1 + rank, num_public_inputs=args.public_inputs,
+                                hasher=1 if args.hasher == "poseidon" else 0)
         blob, wires = made[0], made[1]
         pis = made[2] if args.public_inputs else ()
     S = 1 if sharded else max(1, min(args.in_flight, args.steps))
@@ -378,7 +382,7 @@ def main():
                 "workload": (f"synth(d={d},{mix})" if args.workload == "synth" else f"SHA-256 of a {args.sha_blocks}-block message: {args.sha_blocks} "
                              f"chained Sha256Compression opcodes through the restated reference translator (translate.py)") +
                             f": {1 << d} gates -> 2^{d + 3} LDE rows, {W} wires / 80 routed, "
-                            f"KeccakGoldilocksConfig, rate 8, cap 2^4, 28 queries, 16 PoW bits (BASELINE configs[2] shape)",
+                            f"{'Poseidon' if args.hasher == 'poseidon' else 'Keccak'}GoldilocksConfig, rate 8, cap 2^4, 28 queries, 16 PoW bits (BASELINE configs[2] shape)",
                 "degree_bits": d, "lde_rows": 1 << (d + 3), "mix": mix, "public_inputs": args.public_inputs,
                 "parallelism": (f"one proof coset-sharded over {world} GPUs (8/{world} LDE cosets each; RCCL all-gather of caps, "
                                 f"quotient interpolants, query openings)" if sharded else

@@ -38,7 +38,9 @@
  *     [6] num_selectors             [7] num_challenges    [8] quotient_degree_factor
  *     [9] rate_bits                 [10] cap_height       [11] proof_of_work_bits
  *     [12] num_query_rounds         [13] number of FRI reduction steps
- *     [14..21] reduction_arity_bits [22] hasher (0 = KeccakHash<25>)
+ *     [14..21] reduction_arity_bits [22] hasher: 0 = KeccakHash<25> (the reference's KeccakGoldilocksConfig),
+ *                                        1 = PoseidonHash (PoseidonGoldilocksConfig: Poseidon Merkle trees,
+ *                                        challenger and circuit digest; digests are 4 field elements = 32 bytes)
  *     [23] num_gates                [24] num_public_inputs
  *     [25] flags: bit0 = circuit_digest present, bit1 = constants_sigmas_cap present
  *     [26] num_partial_products     [32..39] circuit_digest (25 bytes used)
@@ -101,9 +103,12 @@ int p2gpu_init(const int *device_ids, int n_devices);
 
 int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out);
 void p2gpu_circuit_destroy(p2gpu_circuit *c);
-/* 2^cap_height x 25 bytes */
+/* bytes of one digest of this circuit's hasher: 25 (KeccakHash<25>) or 32 (PoseidonHash) */
+int p2gpu_circuit_hash_bytes(const p2gpu_circuit *c);
+/* 2^cap_height x hash_bytes */
 int p2gpu_circuit_cap(const p2gpu_circuit *c, uint8_t *out);
-int p2gpu_circuit_digest(const p2gpu_circuit *c, uint8_t out[25]);
+/* hash_bytes */
+int p2gpu_circuit_digest(const p2gpu_circuit *c, uint8_t *out);
 /* HIP device index the handle lives on (< 0: verifier-only handle / bad argument) */
 int p2gpu_circuit_device(const p2gpu_circuit *c);
 /* upper bound of the proof size in bytes for this circuit */

@@ -20,6 +20,7 @@ void orc_keccak_permutation(uint64_t st[12]) { keccak_permutation(st); }
 void orc_poseidon_permute(uint64_t st[12]) { poseidon_permute(st); }
 void orc_poseidon_round_constants(uint64_t out[360]) { memcpy(out, poseidon_round_constants(), 360 * 8); }
 void orc_poseidon_hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4]) { poseidon_hash_no_pad(in, n, out); }
+void orc_set_hasher(int hasher) { g_hasher = hasher == 1; } /* for the stage-level helpers below */
 void orc_commit_values(const uint64_t *vals, size_t ncols, unsigned d, unsigned rate_bits, unsigned cap_h, uint8_t *cap) {
   batch_t b;
   batch_from_values(&b, vals, ncols, d, rate_bits, cap_h);

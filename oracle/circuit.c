@@ -136,7 +136,7 @@ int circuit_parse(circuit_t *c, const uint8_t *blob, size_t len) {
   c->flags = h[25];
   c->num_pp = h[26];
   memcpy(c->digest_in, &h[32], 32);
-  if (c->d > 26 || c->n_steps > 8 || c->hasher != 0 || c->num_challenges > 4) return -3;
+  if (c->d > 26 || c->n_steps > 8 || c->hasher > 1 || c->num_challenges > 4) return -3;
   c->n = (size_t)1 << c->d;
   c->N = c->n << c->rate_bits;
   size_t off = 4 * BLOB_HEADER_WORDS;

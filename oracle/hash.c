@@ -69,7 +69,18 @@ void keccak256(const uint8_t *in, size_t len, uint8_t out[32]) {
 
 /* hash/keccak.rs KeccakHash<N>::hash_no_pad: Keccak-256 over the canonical
  * little-endian u64 encodings, truncated to N = 25 bytes. */
+int g_hasher = 0;
+static digest_t from_elems(const gl_t e[4]) {
+  digest_t d;
+  for (int i = 0; i < 4; i++) memcpy(d.b + 8 * i, &e[i], 8);
+  return d;
+}
 digest_t kh_hash_no_pad(const gl_t *elems, size_t n) {
+  if (g_hasher) { /* PoseidonHash::hash_no_pad = hash_n_to_hash_no_pad (hash/hashing.rs) */
+    gl_t o[4];
+    poseidon_hash_no_pad(elems, n, o);
+    return from_elems(o);
+  }
   uint8_t h[32];
   digest_t d;
   /* field elements are stored canonical; host is little-endian */
@@ -79,6 +90,14 @@ digest_t kh_hash_no_pad(const gl_t *elems, size_t n) {
 }
 /* hash/hash_types.rs + plonk/config.rs Hasher::hash_or_noop */
 digest_t kh_hash_or_noop(const gl_t *elems, size_t n) {
+  if (g_hasher) { /* HashOut::from_partial when the leaf has at most 4 elements */
+    if (n <= 4) {
+      gl_t e[4] = {0, 0, 0, 0};
+      for (size_t i = 0; i < n; i++) e[i] = elems[i];
+      return from_elems(e);
+    }
+    return kh_hash_no_pad(elems, n);
+  }
   if (8 * n <= DIGEST_BYTES) {
     digest_t d;
     memset(d.b, 0, DIGEST_BYTES);
@@ -88,7 +107,15 @@ digest_t kh_hash_or_noop(const gl_t *elems, size_t n) {
   return kh_hash_no_pad(elems, n);
 }
 digest_t kh_two_to_one(const digest_t *l, const digest_t *r) {
-  uint8_t buf[2 * DIGEST_BYTES], h[32];
+  if (g_hasher) { /* hash/hashing.rs compress: state = l || r || 0^4, one permutation, first 4 elements */
+    gl_t st[12];
+    memset(st, 0, sizeof st);
+    memcpy(st, l->b, 32);
+    memcpy(st + 4, r->b, 32);
+    poseidon_permute(st);
+    return from_elems(st);
+  }
+  uint8_t buf[2 * 25], h[32];
   digest_t d;
   memcpy(buf, l->b, DIGEST_BYTES);
   memcpy(buf + DIGEST_BYTES, r->b, DIGEST_BYTES);
@@ -109,6 +136,10 @@ digest_t kh_hash_pad(const gl_t *elems, size_t n) {
   return d;
 }
 void digest_to_elems(const digest_t *d, gl_t out[4]) {
+  if (g_hasher) { /* HashOut: its four elements */
+    memcpy(out, d->b, 32);
+    return;
+  }
   for (int i = 0; i < 4; i++) {
     uint64_t w = 0;
     int len = (i < 3) ? 7 : 4;
@@ -240,10 +271,15 @@ void poseidon_hash_no_pad(const gl_t *in, size_t n, gl_t out[4]) {
 /* ------------------------------------------------------------------------ */
 /* iop/challenger.rs */
 void ch_init(challenger_t *c) { memset(c, 0, sizeof *c); }
+/* the sponge permutation of the configured hasher (Challenger<F, H>: H::Permutation) */
+void hasher_permutation(gl_t st[12]) {
+  if (g_hasher) poseidon_permute(st);
+  else keccak_permutation(st);
+}
 static void ch_duplex(challenger_t *c) {
   for (int i = 0; i < c->n_in; i++) c->state[i] = c->in[i];
   c->n_in = 0;
-  keccak_permutation(c->state);
+  hasher_permutation(c->state);
   for (int i = 0; i < 8; i++) c->out[i] = c->state[i];
   c->n_out = 8;
 }

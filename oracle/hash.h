@@ -16,9 +16,15 @@
 #define ORACLE_HASH_H
 #include "gl.h"
 
-#define DIGEST_BYTES 25
+/* Hasher of the Merkle trees, the challenger and the circuit digest: 0 = KeccakHash<25> (the reference's
+ * KeccakGoldilocksConfig, plonky2-backend/src/lib.rs:13), 1 = PoseidonHash (PoseidonGoldilocksConfig: digests
+ * are 4 field elements = 32 bytes, the challenger permutes with Poseidon).  A process-wide mode: every API
+ * entry point sets it from the circuit it is handed before doing anything (the tests use one circuit at a time). */
+extern int g_hasher;
+#define DIGEST_MAX 32
+#define DIGEST_BYTES (g_hasher ? 32 : 25)
 typedef struct {
-  uint8_t b[DIGEST_BYTES];
+  uint8_t b[DIGEST_MAX];
 } digest_t;
 
 void keccak_f1600(uint64_t st[25]);
@@ -35,6 +41,8 @@ void digest_to_elems(const digest_t *d, gl_t out[4]);
 
 /* KeccakPermutation::permute on 12 field elements */
 void keccak_permutation(gl_t st[12]);
+/* permutation of the configured hasher (g_hasher) */
+void hasher_permutation(gl_t st[12]);
 
 /* Poseidon */
 void poseidon_init(void);

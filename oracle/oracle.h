@@ -51,12 +51,14 @@ typedef struct {
 
 int orc_circuit_create(const uint8_t *blob, size_t len, orc_circuit **out);
 /* verifier-only handle (VerifierCircuitData): cap = 2^cap_height x 25 B, no commitment work */
-int orc_circuit_create_verifier(const uint8_t *blob, size_t len, const uint8_t *cap, const uint8_t digest[25],
+int orc_circuit_create_verifier(const uint8_t *blob, size_t len, const uint8_t *cap, const uint8_t *digest,
                                 orc_circuit **out);
 void orc_circuit_destroy(orc_circuit *c);
 /* copies 2^cap_height digests of 25 bytes each */
 void orc_circuit_cap(const orc_circuit *c, uint8_t *out);
-void orc_circuit_digest(const orc_circuit *c, uint8_t out[25]);
+void orc_circuit_digest(const orc_circuit *c, uint8_t *out /* 25 B (Keccak) or 32 B (Poseidon hasher) */);
+/* hasher of the stage-level helpers (orc_commit_values, orc_merkle_cap, orc_challenger_squeeze): 0 Keccak, 1 Poseidon */
+void orc_set_hasher(int hasher);
 
 /* wires: [num_wires][n] column-major canonical u64.  pow_hint: UINT64_MAX =
  * search for the minimum witness, otherwise use the given witness. */

@@ -47,6 +47,7 @@ int orc_circuit_create(const uint8_t *blob, size_t len, orc_circuit **out) {
   oc->blob = (uint8_t *)malloc(len);
   memcpy(oc->blob, blob, len);
   poseidon_init(); /* not thread-safe: force it before any OpenMP region */
+  if (len >= 256) g_hasher = ((const uint32_t *)oc->blob)[22] == 1;
   int rc = circuit_load(&oc->c, oc->blob, len);
   if (rc) {
     circuit_free(&oc->c);
@@ -57,13 +58,14 @@ int orc_circuit_create(const uint8_t *blob, size_t len, orc_circuit **out) {
   *out = oc;
   return ORC_OK;
 }
-int orc_circuit_create_verifier(const uint8_t *blob, size_t len, const uint8_t *cap, const uint8_t digest[25],
+int orc_circuit_create_verifier(const uint8_t *blob, size_t len, const uint8_t *cap, const uint8_t *digest,
                                 orc_circuit **out) {
   orc_circuit *oc = (orc_circuit *)calloc(1, sizeof *oc);
   /* only the header, gate table and k_is are needed: keep a private copy of the whole blob */
   oc->blob = (uint8_t *)malloc(len);
   memcpy(oc->blob, blob, len);
   poseidon_init();
+  if (len >= 256) g_hasher = ((const uint32_t *)oc->blob)[22] == 1;
   int rc = circuit_load_verifier(&oc->c, oc->blob, len, cap, digest);
   if (rc) {
     circuit_free(&oc->c);
@@ -81,10 +83,14 @@ void orc_circuit_destroy(orc_circuit *oc) {
   free(oc);
 }
 void orc_circuit_cap(const orc_circuit *oc, uint8_t *out) {
+  g_hasher = oc->c.hasher == 1;
   size_t ncap = (size_t)1 << oc->c.cap_height;
   for (size_t i = 0; i < ncap; i++) memcpy(out + DIGEST_BYTES * i, oc->c.cs.tree.cap[i].b, DIGEST_BYTES);
 }
-void orc_circuit_digest(const orc_circuit *oc, uint8_t out[25]) { memcpy(out, oc->c.circuit_digest.b, DIGEST_BYTES); }
+void orc_circuit_digest(const orc_circuit *oc, uint8_t *out) {
+  g_hasher = oc->c.hasher == 1;
+  memcpy(out, oc->c.circuit_digest.b, DIGEST_BYTES);
+}
 const circuit_t *orc_circuit_inner(const orc_circuit *oc) { return &oc->c; }
 
 /* ---- byte buffer ---- */
@@ -152,6 +158,7 @@ typedef struct {
 int orc_prove(const orc_circuit *oc, const uint64_t *wires, const uint64_t *pis, uint32_t n_pi, uint64_t pow_hint,
               uint8_t *proof_out, size_t *proof_len, orc_trace *tr) {
   const circuit_t *c = &oc->c;
+  g_hasher = c->hasher == 1;
   const size_t n = c->n, N = c->N;
   const unsigned d = c->d, rb = c->rate_bits, lgN = d + rb, chh = c->cap_height;
   const size_t W = c->num_wires, R = c->num_routed, K = c->num_challenges, QF = c->qdf, NC = c->num_constants;
@@ -435,7 +442,7 @@ int orc_prove(const orc_circuit *oc, const uint64_t *wires, const uint64_t *pis,
           gl_t st[12];
           memcpy(st, inter, sizeof st);
           st[pos] = w;
-          keccak_permutation(st);
+          hasher_permutation(st);
           if (c->pow_bits == 0 || (st[7] >> (64 - c->pow_bits)) == 0) {
 #pragma omp critical
             if (w < found) found = w;

@@ -109,14 +109,15 @@ class OracleCircuit:
             raise ValueError(f"orc_circuit_create failed: {rc}")
         hdr = self._blob[:256].view(np.uint32)
         self.cap_height = int(hdr[10])
+        self.hash_bytes = 32 if int(hdr[22]) == 1 else 25   # PoseidonHash digests are 4 field elements
 
     def cap(self):
-        out = np.zeros(25 << self.cap_height, dtype=np.uint8)
+        out = np.zeros(self.hash_bytes << self.cap_height, dtype=np.uint8)
         lib().orc_circuit_cap(self._h, out.ctypes.data)
         return out.tobytes()
 
     def digest(self):
-        out = np.zeros(25, dtype=np.uint8)
+        out = np.zeros(self.hash_bytes, dtype=np.uint8)
         lib().orc_circuit_digest(self._h, out.ctypes.data)
         return out.tobytes()
 

@@ -88,6 +88,7 @@ static ext_t compute_evaluation(gl_t x, size_t x_in_coset, unsigned ab, const ex
 
 int orc_verify(const orc_circuit *oc, const uint8_t *proof, size_t len, orc_trace *tr) {
   const circuit_t *c = orc_circuit_inner(oc);
+  g_hasher = c->hasher == 1;
   const size_t n = c->n, N = c->N;
   const unsigned d = c->d, rb = c->rate_bits, lgN = d + rb, chh = c->cap_height;
   const size_t W = c->num_wires, R = c->num_routed, K = c->num_challenges, QF = c->qdf, NC = c->num_constants;

@@ -515,3 +515,58 @@ def test_coset_sharded_proof_over_rccl(pkg, orc, gpu, world, d, mix):
     expect, _ = orc.OracleCircuit(blob).prove(wires)
     for rank, proof, same in res:
         assert same and proof == expect, rank
+
+
+# ---- X1: PoseidonGoldilocksConfig (Poseidon Merkle trees, challenger, digest) ---------------------------
+@pytest.mark.parametrize("d,mix,npi", [(5, "arith", 0), (8, "ecdsa", 3), (10, "sha", 0), (13, "ecdsa", 0), (14, "sha", 4)])
+def test_poseidon_hasher_proofs_match_oracle(pkg, orc, gpu, d, mix, npi):
+    """hasher = 1 in the blob: every Merkle tree (leaves absorbed 8 elements per Poseidon permutation, nodes =
+    compress(l, r)), the Fiat-Shamir challenger, the PoW grind and the circuit digest use Poseidon-Goldilocks
+    instead of Keccak-256/25 -- the north_star's "Poseidon-GL Merkle-tree hashing" mode (the reference itself
+    runs KeccakGoldilocksConfig, lib.rs:13).  GPU proof == oracle proof, both verifiers accept, and the
+    compressed format round-trips with 32-byte digests."""
+    out = pkg.make_circuit(d, mix, 43, num_public_inputs=npi, hasher=1)
+    blob, wires = out[0], out[1]
+    pis = out[2] if npi else ()
+    cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
+    assert cd.hash_bytes() == 32
+    assert cd.constants_sigmas_cap() == oc.cap() and cd.circuit_digest() == oc.digest()
+    expect, tr = oc.prove(wires, public_inputs=pis)
+    got = cd.prove(wires, public_inputs=pis)
+    assert got.timings["pow_witness"] == tr.pow_witness
+    assert got.to_bytes() == expect
+    assert oc.verify(expect)
+    cd.verify(got)
+    vd = cd.verifier_data()
+    vd.verify(got)
+    comp = cd.compress(got)
+    assert cd.decompress(comp).to_bytes() == expect
+    vd.verify_compressed(comp)
+    import torch
+    assert cd.prove(torch.from_numpy(wires.view(np.int64)).cuda(), public_inputs=pis).to_bytes() == expect
+    bad = bytearray(expect)
+    bad[40] ^= 1
+    with pytest.raises(pkg.P2GpuError):
+        cd.verify(bytes(bad))
+    # the same circuit under the reference's Keccak configuration gives a different (and shorter) proof
+    kb = blob.copy()
+    kb[:256].view(np.uint32)[22] = 0
+    ck = pkg.CircuitData(kb)
+    assert ck.hash_bytes() == 25 and len(ck.prove(wires, public_inputs=pis)) < len(expect)
+    ck.close()
+    cd.close()
+
+
+def test_poseidon_hasher_full_size_and_sharded_exercise(pkg, orc, gpu):
+    """2^20 LDE rows with the Poseidon hasher: verifier acceptance (the oracle would take minutes), and the
+    exchange steps of a sharded proof through RCCL with 32-byte digests."""
+    blob, wires = pkg.make_circuit(17, "sha", 1, hasher=1)
+    cd = pkg.CircuitData(blob)
+    proof = cd.prove(wires)
+    ov = orc.OracleCircuit(blob, verifier_cap=cd.constants_sigmas_cap(), verifier_digest=cd.circuit_digest())
+    assert ov.verify(proof.to_bytes())
+    cd.verifier_data().verify(proof)
+    cd.set_shard(0, 1, transport="rccl")
+    cd.set("shard_exercise", 1)
+    assert cd.prove(wires).to_bytes() == proof.to_bytes()
+    cd.close()

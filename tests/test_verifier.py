@@ -23,15 +23,16 @@ def vk_blob(blob, cap, digest):
     ng, R, cap_h = int(h[23]), int(h[4]), int(h[10])
     h[25] = 3
     hb = bytearray(h.tobytes())
-    hb[128:128 + 25] = digest
+    nb = len(digest)                  # 25 (KeccakHash<25>) or 32 (PoseidonHash)
+    hb[128:128 + nb] = digest
     gates = blob[256:256 + 48 * ng].tobytes()
-    capb = b"".join(cap[25 * i:25 * (i + 1)] + bytes(7) for i in range(1 << cap_h))
+    capb = b"".join(cap[nb * i:nb * (i + 1)] + bytes(32 - nb) for i in range(1 << cap_h))
     k_is = blob[256 + 48 * ng:256 + 48 * ng + 8 * R].tobytes()
     return bytes(hb) + gates + capb + k_is
 
 
-def make(pkg, orc, d, mix, seed, npi=0, num_wires=234):
-    out = pkg.make_circuit(d, mix, seed, num_public_inputs=npi, num_wires=num_wires)
+def make(pkg, orc, d, mix, seed, npi=0, num_wires=234, hasher=0):
+    out = pkg.make_circuit(d, mix, seed, num_public_inputs=npi, num_wires=num_wires, hasher=hasher)
     blob, wires = out[0], out[1]
     pis = out[2] if npi else ()
     oc = orc.OracleCircuit(blob)
@@ -192,3 +193,30 @@ def test_garbage_never_crashes_the_host_parsers(pkg, orc):
         for fn in (vd.verify, vd.verify_compressed, vd.decompress, vd.compress):
             with pytest.raises(pkg.P2GpuError):
                 fn(blob)
+
+
+@pytest.mark.parametrize("d,mix,npi", [(5, "arith", 0), (8, "ecdsa", 3), (10, "sha", 0)])
+def test_poseidon_hasher_oracle_prover_vs_product_verifier(pkg, orc, d, mix, npi):
+    """PoseidonGoldilocksConfig (blob hasher = 1): Poseidon Merkle trees / challenger / circuit digest.  The
+    oracle's prover and the product's host verifier are independent implementations of that mode too: the
+    verifier accepts the oracle's proofs, rejects tampered ones, and the compressed format round-trips with
+    32-byte digests.  (The reference itself runs KeccakGoldilocksConfig, plonky2-backend/src/lib.rs:13.)"""
+    oc, vd, wires, pis = make(pkg, orc, d, mix, 9, npi, hasher=1)
+    assert vd.hash_bytes() == 32 and len(oc.digest()) == 32
+    proof, _ = oc.prove(wires, public_inputs=pis)
+    assert oc.verify(proof)
+    vd.verify(proof)
+    comp = vd.compress(proof)
+    assert len(comp) < len(proof) and vd.decompress(comp).to_bytes() == proof
+    vd.verify_compressed(comp)
+    rng = np.random.default_rng(3)
+    for off in [int(x) for x in rng.integers(0, len(proof), size=12)]:
+        bad = bytearray(proof)
+        bad[off] ^= 1 << int(rng.integers(0, 8))
+        assert not oc.verify(bytes(bad))
+        with pytest.raises(pkg.P2GpuError):
+            vd.verify(bytes(bad))
+    # a Keccak verifier key does not accept a Poseidon proof of the same circuit
+    ock, vdk, _, _ = make(pkg, orc, d, mix, 9, npi, hasher=0)
+    with pytest.raises(pkg.P2GpuError):
+        vdk.verify(proof)

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void pow_kernel(PowState st0, uint32_t pos, ui
       } else {
         st[0] = poseidon_sbox(st[0]);
       }
-      poseidon_mds(st);
+      poseidon_mds_dev(st);
     }
   } else {
     keccak_permutation12(st);

@@ -33,7 +33,7 @@ __device__ __forceinline__ void poseidon_permute_dev(gl_t st[12], const gl_t *__
     } else {
       st[0] = poseidon_sbox(st[0]);
     }
-    poseidon_mds(st);
+    poseidon_mds_dev(st);
   }
 }
 // hash_n_to_m_no_pad: overwrite-mode sponge, 8 elements per permutation, first 4 words out

@@ -78,6 +78,29 @@ P2_HD void poseidon_mds(gl_t st[12]) {
 #endif
   for (int i = 0; i < 12; i++) st[i] = r[i];
 }
+#if defined(__HIPCC__)
+// the same linear layer on the device: the MDS entries are < 2^6, so a row is two 64-bit dot products over the
+// 32-bit halves of the state (one v_mad_u64_u32 per term and half) and ONE reduction, instead of 13 128-bit
+// multiply-accumulates: 30 layers x 12 rows make this the bulk of a permutation
+__device__ __forceinline__ void poseidon_mds_dev(gl_t st[12]) {
+  gl_t r[12];
+#pragma unroll
+  for (int row = 0; row < 12; row++) {
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      const uint32_t k = POSEIDON_MDS_CIRC[i] + ((row == 0 && i == 0) ? POSEIDON_MDS_DIAG0 : 0);
+      const gl_t v = st[(i + row) % 12];
+      lo += (uint64_t)(uint32_t)v * k;
+      hi += (v >> 32) * k;
+    }
+    const uint64_t l = lo + (hi << 32);
+    r[row] = gl_reduce128(l, (hi >> 32) + (l < lo));
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) st[i] = r[i];
+}
+#endif
 P2_HD gl_t poseidon_sbox(gl_t x) {
   gl_t x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x2, x);
   return gl_mul(x4, x3);

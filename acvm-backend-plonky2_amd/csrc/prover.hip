@@ -1363,6 +1363,25 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
   const double t0 = now_ms();
   const uint32_t W = c->W, chunk = 34;  // two rate blocks
   const size_t n = c->n;
+  if (c->shard_world > 1) {
+    // Sharded proof, witness in host memory: a rank pulls only ITS block of columns
+    // [q * cpr, (q + 1) * cpr) across its own PCIe link -- W / G columns, 31 MB instead of 245 MB at d = 17 and
+    // G = 8 -- and the blocks are exchanged GPU to GPU with one in-place all-gather (xGMI on a real node).
+    // The inverse transform then runs replicated on every rank: at 0.5 ms it is cheaper than a second
+    // exchange of the same 245 MB as coefficients would be.
+    const uint32_t G = (uint32_t)c->shard_world, q = (uint32_t)c->shard_rank, cpr = (W + G - 1) / G;
+    if (c->wires_vals.count < (size_t)G * cpr * n) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      c->wires_vals.release();
+      HIP_TRY(c->wires_vals.alloc((size_t)G * cpr * n));
+    }
+    const uint32_t c0 = std::min(q * cpr, W), c1 = std::min((q + 1) * cpr, W);
+    if (c1 > c0)
+      HIP_TRY(hipMemcpyAsync(c->wires_vals.p + (size_t)c0 * n, wires + (size_t)c0 * n, 8 * (size_t)(c1 - c0) * n, hipMemcpyHostToDevice,
+                             c->stream));
+    if (int rc = shard_allgather(c, c->wires_vals.p + (size_t)q * cpr * n, c->wires_vals.p, 8 * (size_t)cpr * n)) return rc;
+    return prove_impl(c, c->wires_vals.p, pis, n_pi, proof_out, proof_len, tm, now_ms() - t0);
+  }
   const gl_t ninv = gl_inv((gl_t)n);
   Batch &b = c->wires;
   // (also implies a hashed leaf: more than 3 columns); the chunk-wise sponge is the Keccak one (17-column rate blocks)

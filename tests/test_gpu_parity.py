@@ -347,9 +347,16 @@ def _shard_worker(rank, world, port, d, mix, npi, q):
     cd.set_shard(rank, world)
     p1 = cd.prove(wires, public_inputs=pis).to_bytes()
     p2 = cd.prove(torch.from_numpy(wires.view(np.int64)).cuda(), public_inputs=pis).to_bytes()
+    # host witness in sharded mode: a rank reads only ITS block of columns -- the rest
+    # of the matrix it is handed may be garbage, the blocks are all-gathered between the GPUs
+    cpr = -(-wires.shape[0] // world)
+    own = wires.copy()
+    own[:rank * cpr] = 0xDEADBEEF
+    own[(rank + 1) * cpr:] = 0xDEADBEEF
+    p3 = cd.prove(own, public_inputs=pis).to_bytes()
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, p1, p1 == p2))
+    q.put((rank, p1, p1 == p2 == p3))
 
 
 @pytest.mark.parametrize("world,d,mix,npi", [(2, 8, "ecdsa", 0), (2, 13, "sha", 4), (4, 9, "arith", 0), (8, 10, "ecdsa", 0)])

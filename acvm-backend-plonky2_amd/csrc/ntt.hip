@@ -223,29 +223,53 @@ __device__ __forceinline__ void round_regs(gl_t *lds, const PassArgs &A, uint32_
   constexpr int R = 1 << LOGR;
   const uint32_t ngroups = 1u << (TB - LOGR);
   const uint32_t s0 = beta0 - A.tb + A.s;  // log2 M
-  const uint32_t M = 1u << s0;
+  // Index arithmetic is a tenth of this kernel's instructions if done per access: the padded LDS index
+  // e + (e >> 4) of element base | (j << beta0) is LINEAR in j whenever the round's bits lie entirely above
+  // or entirely below bit 4 (every round of the d = 17 plans), and the packed twiddle table is walked with
+  // one 64-bit add per entry.
+  const bool linear = beta0 >= 4 || beta0 + LOGR <= 4;
+  const uint32_t lstride = beta0 >= 4 ? (1u << beta0) + (1u << (beta0 - 4)) : (1u << beta0);
+  const size_t tstride = (size_t)1 << s0;
   for (uint32_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
     const uint32_t low = g & ((1u << beta0) - 1), high = g >> beta0;
     const uint32_t base = (high << (beta0 + LOGR)) | low;
     const uint32_t lo = (((base & ((1u << beta0) - 1)) >> A.tb) << A.s) + lo0 + (base & ((1u << A.tb) - 1));
     gl_t v[R];
+    uint32_t li[R];
+    if (linear) {
+      const uint32_t l0 = pidx(base);
 #pragma unroll
-    for (int j = 0; j < R; j++) v[j] = lds[pidx(base | ((uint32_t)j << beta0))];
+      for (int j = 0; j < R; j++) li[j] = l0 + (uint32_t)j * lstride;
+    } else {
+#pragma unroll
+      for (int j = 0; j < R; j++) li[j] = pidx(base | ((uint32_t)j << beta0));
+    }
+#pragma unroll
+    for (int j = 0; j < R; j++) v[j] = lds[li[j]];
+    gl_t t[R];  // t[e]: twiddle of table row e - 1
+    if constexpr (MUL) {
+      const gl_t *tp = tw + lo;
+#pragma unroll
+      for (int e = 1; e < R; e++) {
+        t[e] = *tp;
+        tp += tstride;
+      }
+    }
     if constexpr (DIT && MUL) {
       static_for<1, R>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        v[j] = gl_mul(v[j], tw[(size_t)(brev_c(j, LOGR) - 1) * M + lo]);
+        v[j] = gl_mul(v[j], t[brev_c(j, LOGR)]);
       });
     }
     dft_regs<LOGR, DIT, INV>(v);
     if constexpr (!DIT && MUL) {
       static_for<1, R>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        v[j] = gl_mul(v[j], tw[(size_t)(brev_c(j, LOGR) - 1) * M + lo]);
+        v[j] = gl_mul(v[j], t[brev_c(j, LOGR)]);
       });
     }
 #pragma unroll
-    for (int j = 0; j < R; j++) lds[pidx(base | ((uint32_t)j << beta0))] = v[j];
+    for (int j = 0; j < R; j++) lds[li[j]] = v[j];
   }
 }
 #endif
@@ -296,13 +320,20 @@ __global__ __launch_bounds__(256, NTT_MIN_WAVES) void ntt_pass_kernel(PassArgs A
   gl_t *dst = A.dst + ((size_t)coset * A.cols + col) * n;
   const gl_t *scale = A.scale ? A.scale + (size_t)(A.coset_first + coset * A.coset_stride) * n : nullptr;
   const uint32_t tsize = 1u << TB;
+  // lane e + i * NT of the tile: when a contiguous run (2^tb elements) divides NT = 256, the global index is
+  // linear in i (g0 + i * gstep) and so is the padded LDS index (l0 + i * 272): one add per access
+  constexpr int NT12 = 256;
+  const bool glin = A.tb <= 8;
+  const uint32_t g0 = gidx(threadIdx.x, hi_base, lo0, A.s, A.tb), gstep = (NT12 >> (glin ? A.tb : 0)) << A.s;
+  const uint32_t l0 = pidx(threadIdx.x);
   if constexpr (TBC != 0) {
     constexpr int PER = 16, NT = (1 << TBC) / PER;
+    static_assert(NT == NT12, "tile of 2^12 elements, 256 lanes");
     gl_t x[PER];
     uint32_t g[PER];
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-      g[i] = gidx(threadIdx.x + i * NT, hi_base, lo0, A.s, A.tb);
+      g[i] = glin ? g0 + (uint32_t)i * gstep : gidx(threadIdx.x + i * NT, hi_base, lo0, A.s, A.tb);
       x[i] = src[g[i]];
     }
     if (scale) {
@@ -313,7 +344,7 @@ __global__ __launch_bounds__(256, NTT_MIN_WAVES) void ntt_pass_kernel(PassArgs A
       for (int i = 0; i < PER; i++) x[i] = gl_mul(x[i], sc[i]);
     }
 #pragma unroll
-    for (int i = 0; i < PER; i++) lds[pidx(threadIdx.x + i * NT)] = x[i];
+    for (int i = 0; i < PER; i++) lds[l0 + (uint32_t)i * (NT + NT / 16)] = x[i];
   } else {
     for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
       const uint32_t g = gidx(e, hi_base, lo0, A.s, A.tb);
@@ -343,20 +374,26 @@ __global__ __launch_bounds__(256, NTT_MIN_WAVES) void ntt_pass_kernel(PassArgs A
     constexpr int PER = 16, NT = (1 << TBC) / PER;
     gl_t x[PER];
 #pragma unroll
-    for (int i = 0; i < PER; i++) x[i] = lds[pidx(threadIdx.x + i * NT)];
+    for (int i = 0; i < PER; i++) x[i] = lds[l0 + (uint32_t)i * (NT + NT / 16)];
     if (post) {
 #pragma unroll
       for (int i = 0; i < PER; i++) x[i] = gl_mul(x[i], A.post);
     } else {
+#if NTT_PHI
 #pragma unroll
       for (int i = 0; i < PER; i++) x[i] = gl_canon(x[i]);  // LDS holds congruent, not canonical, words
+#endif
     }
 #pragma unroll
-    for (int i = 0; i < PER; i++) dst[gidx(threadIdx.x + i * NT, hi_base, lo0, A.s, A.tb)] = x[i];
+    for (int i = 0; i < PER; i++) dst[glin ? g0 + (uint32_t)i * gstep : gidx(threadIdx.x + i * NT, hi_base, lo0, A.s, A.tb)] = x[i];
   } else {
     for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
       gl_t x = lds[pidx(e)];
+#if NTT_PHI
       x = post ? gl_mul(x, A.post) : gl_canon(x);
+#else
+      if (post) x = gl_mul(x, A.post);
+#endif
       dst[gidx(e, hi_base, lo0, A.s, A.tb)] = x;
     }
   }

@@ -21,6 +21,7 @@ from .prover import (  # noqa: F401
     lde_batch,
     commit_values,
     hash_rows,
+    field_selftest,
     lib_path,
     load_library,
 )

@@ -30,26 +30,176 @@ constexpr uint64_t GL_EPS = 0xFFFFFFFFULL;
 constexpr uint64_t GL_GEN = 14293326489335486720ULL;  // MULTIPLICATIVE_GROUP_GENERATOR = coset shift
 constexpr uint64_t GL_ROOT_2_32 = 7277203076849721926ULL;   // POWER_OF_TWO_GENERATOR = GL_GEN^((p-1)/2^32); w_64 = 8
 
-P2_HD gl_t gl_canon(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
-P2_HD gl_t gl_add(gl_t a, gl_t b) {
+#ifndef P2_GL_ASM
+#define P2_GL_ASM 1  // 1: carry-chain formulations below on the device; 0: what hipcc makes of the portable code
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && P2_GL_ASM
+#define P2_GL_DEV_ASM 1
+#else
+#define P2_GL_DEV_ASM 0
+#endif
+
+// ---- portable forms (host; device reference for the self-test) -------------------------------------------
+P2_HD gl_t gl_canon_c(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
+P2_HD gl_t gl_add_c(gl_t a, gl_t b) {
   uint64_t s = a + b;
   if (s < a || s >= GL_P) s -= GL_P;
   return s;
 }
-P2_HD gl_t gl_sub(gl_t a, gl_t b) { return a >= b ? a - b : a - b + GL_P; }
-P2_HD gl_t gl_neg(gl_t a) { return a ? GL_P - a : 0; }
-P2_HD gl_t gl_dbl(gl_t a) { return gl_add(a, a); }
-
+P2_HD gl_t gl_sub_c(gl_t a, gl_t b) { return a >= b ? a - b : a - b + GL_P; }
 // reduce hi:lo (a 128-bit value) mod p -> canonical
-P2_HD gl_t gl_reduce128(uint64_t lo, uint64_t hi) {
+P2_HD gl_t gl_reduce128_c(uint64_t lo, uint64_t hi) {
   uint64_t hh = hi >> 32, hl = hi & GL_EPS;
   uint64_t t0 = lo - hh;
   if (lo < hh) t0 -= GL_EPS;
   uint64_t t1 = hl * GL_EPS;  // (hl << 32) - hl
   uint64_t t2 = t0 + t1;
   if (t2 < t1) t2 += GL_EPS;
-  return gl_canon(t2);
+  return gl_canon_c(t2);
 }
+
+// wait states inside the carry chains (experiment knobs, scratch/ubench/hazard.hip): P2_HZ_A_N between a VALU that
+// leaves a carry in an SGPR pair and the scalar instruction that reads it, P2_HZ_B_N between that scalar
+// instruction and the VALU that takes its result as carry-in; 0 = none, 1 = s_nop 0, 2 = s_nop 1
+#ifndef P2_HZ_A_N
+#define P2_HZ_A_N 0
+#endif
+#ifndef P2_HZ_B_N
+#define P2_HZ_B_N 0
+#endif
+#if P2_HZ_A_N == 0
+#define P2_HZ_A ""
+#elif P2_HZ_A_N == 1
+#define P2_HZ_A "s_nop 0\n\t"
+#else
+#define P2_HZ_A "s_nop 1\n\t"
+#endif
+#if P2_HZ_B_N == 0
+#define P2_HZ_B ""
+#elif P2_HZ_B_N == 1
+#define P2_HZ_B "s_nop 0\n\t"
+#else
+#define P2_HZ_B "s_nop 1\n\t"
+#endif
+#if P2_GL_DEV_ASM
+// ---- gfx950 forms ------------------------------------------------------------------------------------------
+// hipcc lowers the portable code to v_lshl_add_u64 / v_cmp_lt_u64 / v_cndmask_b32 triples: 6 VALU per add or
+// sub, 17 per reduction.  Here every wrap of 2^64 (= eps = 2^32 - 1 mod p) is taken from the carry flag the
+// 32-bit add already produced and applied as "x0 -/+= m ; x1 +/-= m & !k" (2 VALU + one s_andn2 on the scalar
+// unit, which does not compete for the vector issue slot): sub 4, add 5, reduction 8 + 3, all canonical in,
+// canonical out.  Carry chains through vcc run back to back like the ones of gl_mul128; a carry an instruction
+// leaves in another SGPR pair is consumed by the scalar unit or at least two instructions later.  The scalar
+// mask instructions write SCC: it is in every clobber list (the compiler keeps compares live across the block).
+P2_HD gl_t gl_join(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+// x >= p ? x - p : x for any u64: x >= p <=> x1 = 2^32 - 1 and x0 >= 1, and then x - p = (0, x0 - 1)
+P2_HD gl_t gl_canon(uint64_t x) {
+  const uint64_t g = __builtin_amdgcn_uicmpl(x, GL_P - 1, 34 /* ICMP_UGT */);
+  uint32_t r0, r1;
+  uint64_t junk;
+  asm("s_nop 1\n\t"  // g comes straight from a v_cmp: two wait states before a VALU reads it
+      "v_subb_co_u32 %0, %2, %3, 0, %5\n\t"
+      "v_addc_co_u32 %1, %2, %4, 0, %5"
+      : "=&v"(r0), "=&v"(r1), "=&s"(junk)
+      : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), "s"(g));
+  return gl_join(r0, r1);
+}
+P2_HD gl_t gl_sub(gl_t a, gl_t b) {
+  uint32_t d0, d1;
+  uint64_t k;
+  asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+      "v_subb_co_u32 %1, vcc, %4, %6, vcc\n\t"   // borrow: the difference wrapped, d + 2^64 = d + p + eps
+      "v_addc_co_u32 %0, %2, %0, 0, vcc\n\t"     // d -= eps: d0 += 1 (carry k) ...
+      P2_HZ_A "s_andn2_b64 vcc, vcc, %2\n\t" P2_HZ_B
+      "v_subb_co_u32 %1, vcc, %1, 0, vcc"          // ... d1 -= 1 - k
+      : "=&v"(d0), "=&v"(d1), "=&s"(k)
+      : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32))
+      : "vcc", "scc");
+  return gl_join(d0, d1);
+}
+P2_HD gl_t gl_add(gl_t a, gl_t b) {
+  uint32_t s0, s1;
+  uint64_t c;
+  asm("v_add_co_u32 %0, vcc, %3, %5\n\t"
+      "v_addc_co_u32 %1, %2, %4, %6, vcc"
+      : "=&v"(s0), "=&v"(s1), "=&s"(c)
+      : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32))
+      : "vcc");
+  // a + b >= p <=> the 64-bit sum wrapped or is >= p; then subtract p = add eps (mod 2^64)
+  const uint64_t m = c | __builtin_amdgcn_uicmpl(gl_join(s0, s1), GL_P - 1, 34);
+  uint32_t r0, r1;
+  uint64_t k;
+  asm("v_subb_co_u32 %0, %2, %3, 0, %5\n\t"      // s0 -= 1 (borrow k) ...
+      P2_HZ_A "s_andn2_b64 %2, %5, %2\n\t" P2_HZ_B
+      "v_addc_co_u32 %1, %2, %4, 0, %2"            // ... s1 += 1 - k
+      : "=&v"(r0), "=&v"(r1), "=&s"(k)
+      : "v"(s0), "v"(s1), "s"(m)
+      : "scc");
+  return gl_join(r0, r1);
+}
+// (w3 w2 w1 w0) mod p = (w1:w0) + w2 * eps - w3  (2^64 = eps, 2^96 = -1).  With c = carry(w1 + w2):
+// ((w1 + w2 + c) : w0) - (w2 + w3 + c), one wrap at most, then the canonical representative.
+P2_HD gl_t gl_reduce_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+  uint32_t r0, r1, y0;
+  uint64_t cy, k;
+  asm("v_add_co_u32 %1, vcc, %6, %7\n\t"          // u1 = w1 + w2, carry c
+      "v_addc_co_u32 %2, %3, %7, %8, vcc\n\t"     // y = w2 + w3 + c (33 bits: carry cy)
+      "v_addc_co_u32 %1, vcc, %1, 0, vcc\n\t"     // u1 += c (cannot carry)
+      "v_sub_co_u32 %0, vcc, %5, %2\n\t"          // r0 = w0 - y0
+      "v_subb_co_u32 %1, vcc, %1, 0, vcc\n\t"     // r1 = u1 - borrow
+      "v_subb_co_u32 %1, %4, %1, 0, %3\n\t"       // r1 -= cy
+      P2_HZ_A "s_or_b64 vcc, vcc, %4\n\t" P2_HZ_B              // wrapped below zero (the two borrows exclude each other)
+      "v_addc_co_u32 %0, %4, %0, 0, vcc\n\t"      // r -= eps
+      P2_HZ_A "s_andn2_b64 vcc, vcc, %4\n\t" P2_HZ_B
+      "v_subb_co_u32 %1, vcc, %1, 0, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(y0), "=&s"(cy), "=&s"(k)
+      : "v"(w0), "v"(w1), "v"(w2), "v"(w3)
+      : "vcc", "scc");
+  return gl_canon(gl_join(r0, r1));
+}
+P2_HD gl_t gl_reduce128(uint64_t lo, uint64_t hi) {
+  return gl_reduce_words((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+// (w1:w0) + w2 * eps
+P2_HD gl_t gl_reduce_add_eps(uint32_t w0, uint32_t w1, uint32_t w2) {
+  uint32_t r0, r1, t0, t1;
+  uint64_t k;
+  asm("v_sub_co_u32 %2, vcc, 0, %7\n\t"           // w2 * eps = (w2 - [w2 != 0]) : -w2
+      "v_subbrev_co_u32 %3, vcc, 0, %7, vcc\n\t"
+      "v_add_co_u32 %0, vcc, %5, %2\n\t"
+      "v_addc_co_u32 %1, vcc, %6, %3, vcc\n\t"    // carry: += eps
+      "v_subb_co_u32 %0, %4, %0, 0, vcc\n\t"
+      P2_HZ_A "s_andn2_b64 vcc, vcc, %4\n\t" P2_HZ_B
+      "v_addc_co_u32 %1, vcc, %1, 0, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(t0), "=&v"(t1), "=&s"(k)
+      : "v"(w0), "v"(w1), "v"(w2)
+      : "vcc", "scc");
+  return gl_canon(gl_join(r0, r1));
+}
+// z * eps - (h1:h0)
+P2_HD gl_t gl_reduce_eps_sub(uint32_t z, uint32_t h0, uint32_t h1) {
+  uint32_t r0, r1, t0, t1;
+  uint64_t k;
+  asm("v_sub_co_u32 %2, vcc, 0, %7\n\t"
+      "v_subbrev_co_u32 %3, vcc, 0, %7, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %2, %5\n\t"
+      "v_subb_co_u32 %1, vcc, %3, %6, vcc\n\t"    // borrow: -= eps
+      "v_addc_co_u32 %0, %4, %0, 0, vcc\n\t"
+      P2_HZ_A "s_andn2_b64 vcc, vcc, %4\n\t" P2_HZ_B
+      "v_subb_co_u32 %1, vcc, %1, 0, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(t0), "=&v"(t1), "=&s"(k)
+      : "v"(h0), "v"(h1), "v"(z)
+      : "vcc", "scc");
+  return gl_canon(gl_join(r0, r1));
+}
+#else
+P2_HD gl_t gl_canon(uint64_t x) { return gl_canon_c(x); }
+P2_HD gl_t gl_add(gl_t a, gl_t b) { return gl_add_c(a, b); }
+P2_HD gl_t gl_sub(gl_t a, gl_t b) { return gl_sub_c(a, b); }
+P2_HD gl_t gl_reduce128(uint64_t lo, uint64_t hi) { return gl_reduce128_c(lo, hi); }
+#endif
+P2_HD gl_t gl_neg(gl_t a) { return a ? GL_P - a : 0; }
+P2_HD gl_t gl_dbl(gl_t a) { return gl_add(a, a); }
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // 64 x 64 -> 128 on gfx950 in 8 VALU: four v_mad_u64_u32 (the cross terms chained through the
 // carry-out SGPR pair) and one 32-bit carry chain.  hipcc's own lowering of the same product

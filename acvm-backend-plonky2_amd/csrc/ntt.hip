@@ -40,6 +40,33 @@ __device__ __forceinline__ void static_for(F &&f) {
 }
 
 // x * 2^E mod p for a compile-time 0 <= E < 96 (canonical in, canonical out)
+#if P2_GL_DEV_ASM
+// x = x0 + x1 * 2^32, E = 32 q + r: the shifted words go straight into the carry-chain reductions of gl.hpp
+// (2^64 = eps, 2^96 = -1): 11-14 VALU for every E, where the portable form below costs 15 (E < 32), 20
+// (E < 64) or 35 (two steps).
+template <int E>
+__device__ __forceinline__ gl_t mul_pow2(gl_t x) {
+  if constexpr (E == 0) {
+    return x;
+  } else if constexpr (E < 32) {
+    const uint64_t lo = x << E;
+    return gl_reduce_add_eps((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)(x >> (64 - E)));
+  } else if constexpr (E == 32) {
+    return gl_reduce_words(0u, (uint32_t)x, (uint32_t)(x >> 32), 0u);
+  } else if constexpr (E < 64) {
+    const uint64_t y = x << (E - 32);
+    return gl_reduce_words(0u, (uint32_t)y, (uint32_t)(y >> 32), (uint32_t)(x >> (96 - E)));
+  } else if constexpr (E == 64) {
+    // x * 2^64 = -x * 2^-32 = x0 * eps - x1
+    return gl_reduce_eps_sub((uint32_t)x, (uint32_t)(x >> 32), 0u);
+  } else {
+    // x * 2^E = -x * 2^-s, s = 96 - E in (0, 32): x 2^-s = (x >> s) - z eps, z = low s bits of x at the top of a word
+    constexpr int S = 96 - E;
+    const uint64_t h = x >> S;
+    return gl_reduce_eps_sub((uint32_t)x << (32 - S), (uint32_t)h, (uint32_t)(h >> 32));
+  }
+}
+#else
 template <int E>
 __device__ __forceinline__ gl_t mul_pow2(gl_t x) {
   if constexpr (E == 0) {
@@ -57,6 +84,7 @@ __device__ __forceinline__ gl_t mul_pow2(gl_t x) {
     return mul_pow2<32>(mul_pow2<E - 32>(x));
   }
 }
+#endif
 
 // exponent of 2 for the constant twiddle w_{2^(lam+1)}^q (w_64 = 2^3), mod 192
 __host__ __device__ constexpr int tw_exp(int lam, int q, bool inv) {
@@ -578,6 +606,50 @@ void fill_coset_scale(hipStream_t st, gl_t *out, gl_t shift, gl_t wN, uint32_t d
   uint32_t n = 1u << d;
   hipLaunchKernelGGL(coset_scale_kernel, dim3((n + 255) / 256, cosets), dim3(256), 0, st, out, shift, wN, d, cosets,
                      mult);
+}
+
+// ---- self-test of the field primitives (stage-level test operator p2gpu_field_selftest) -------------------
+// a[i], b[i]: arbitrary u64.  Every carry-chain form of gl.hpp / mul_pow2 against the portable code, which is
+// what the host and the oracle run: bad[0] canon, [1] add, [2] sub, [3] reduce128, [4] mul, [5] mul_add,
+// [6] mul_pow2<1..95>, [7] Acc160.
+__global__ void field_selftest_kernel(const uint64_t *a, const uint64_t *b, uint32_t n, unsigned long long *bad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t x = a[i], y = b[i];
+  const gl_t xc = gl_canon_c(x), yc = gl_canon_c(y);
+  if (gl_canon(x) != xc) atomicAdd(&bad[0], 1ULL);
+  if (gl_add(xc, yc) != gl_add_c(xc, yc)) atomicAdd(&bad[1], 1ULL);
+  if (gl_sub(xc, yc) != gl_sub_c(xc, yc)) atomicAdd(&bad[2], 1ULL);
+  if (gl_reduce128(x, y) != gl_reduce128_c(x, y)) atomicAdd(&bad[3], 1ULL);
+  const uint64_t plo = xc * yc, phi = __umul64hi(xc, yc);
+  const gl_t prod = gl_reduce128_c(plo, phi);
+  if (gl_mul(xc, yc) != prod) atomicAdd(&bad[4], 1ULL);
+  {
+    uint64_t lo = plo + xc, hi = phi + (lo < xc);
+    if (gl_mul_add(xc, yc, xc) != gl_reduce128_c(lo, hi)) atomicAdd(&bad[5], 1ULL);
+  }
+  gl_t pw = 1;
+  bool ok = true;
+  static_for<1, 96>([&](auto ec) {
+    constexpr int e = decltype(ec)::value;
+    pw = gl_add_c(pw, pw);
+    const uint64_t l = xc * pw, h = __umul64hi(xc, pw);
+    if (mul_pow2<e>(xc) != gl_reduce128_c(l, h)) ok = false;
+  });
+  if (!ok) atomicAdd(&bad[6], 1ULL);
+  {
+    Acc160 acc;
+    acc.clear();
+    acc.mac(xc, yc);
+    acc.mac(yc, yc);
+    acc.mac(xc, xc);
+    const uint64_t l2 = yc * yc, h2 = __umul64hi(yc, yc), l3 = xc * xc, h3 = __umul64hi(xc, xc);
+    const gl_t want = gl_add_c(gl_add_c(prod, gl_reduce128_c(l2, h2)), gl_reduce128_c(l3, h3));
+    if (acc.value() != want) atomicAdd(&bad[7], 1ULL);
+  }
+}
+void field_selftest(hipStream_t st, const uint64_t *a, const uint64_t *b, uint32_t n, unsigned long long *bad) {
+  hipLaunchKernelGGL(field_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, n, bad);
 }
 
 // bit-reversal permutation of columns (only for the stage-level test operators

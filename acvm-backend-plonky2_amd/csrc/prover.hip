@@ -1473,6 +1473,23 @@ int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned r
   return P2GPU_OK;
 } P2GPU_CATCH
 
+int p2gpu_field_selftest(const uint64_t *a, const uint64_t *b, size_t n, uint64_t bad_out[8]) try {
+  if (int rc = ensure_device()) return rc;
+  if (!a || !b || !bad_out || n == 0 || n > ((size_t)1 << 28)) return P2GPU_E_ARG;
+  Scratch S;
+  HIP_TRY(hipStreamCreate(&S.st));
+  uint64_t *da = S.alloc<uint64_t>(n), *db = S.alloc<uint64_t>(n);
+  unsigned long long *bad = S.alloc<unsigned long long>(8);
+  if (!da || !db || !bad) { set_err("hipMalloc failed"); return P2GPU_E_DEVICE; }
+  HIP_TRY(hipMemcpyAsync(da, a, 8 * n, hipMemcpyHostToDevice, S.st));
+  HIP_TRY(hipMemcpyAsync(db, b, 8 * n, hipMemcpyHostToDevice, S.st));
+  HIP_TRY(hipMemsetAsync(bad, 0, 64, S.st));
+  field_selftest(S.st, da, db, (uint32_t)n, bad);
+  HIP_TRY(hipMemcpyAsync(bad_out, bad, 64, hipMemcpyDeviceToHost, S.st));
+  HIP_TRY(hipStreamSynchronize(S.st));
+  return P2GPU_OK;
+} P2GPU_CATCH
+
 int p2gpu_hash_rows(const uint64_t *rows, size_t n_rows, size_t row_len, uint8_t *digests_out) try {
   if (int rc = ensure_device()) return rc;
   if (!rows || !digests_out) return P2GPU_E_ARG;

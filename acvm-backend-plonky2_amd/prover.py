@@ -105,6 +105,7 @@ def load_library():
     lib.p2gpu_lde_batch.argtypes = [vp, sz, ctypes.c_uint, ctypes.c_uint, vp]
     lib.p2gpu_commit_values.argtypes = [vp, sz, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, u8p]
     lib.p2gpu_hash_rows.argtypes = [vp, sz, sz, u8p]
+    lib.p2gpu_field_selftest.argtypes = [vp, vp, sz, vp]
     lib.p2gpu_device_info.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(sz)]
     _LIB = lib
     return lib
@@ -496,6 +497,17 @@ def commit_values(vals, rate_bits=3, cap_height=4):
     out = np.zeros(25 << cap_height, dtype=np.uint8)
     _check(lib.p2gpu_commit_values(v.ctypes.data, ncols, d, rate_bits, cap_height, out.ctypes.data))
     return out.tobytes()
+
+
+def field_selftest(a, b):
+    """Mismatch counters of the device field primitives against the portable code on the word pairs (a[i], b[i])."""
+    lib = load_library()
+    x = np.ascontiguousarray(a, dtype=np.uint64)
+    y = np.ascontiguousarray(b, dtype=np.uint64)
+    assert x.shape == y.shape and x.ndim == 1
+    bad = np.zeros(8, dtype=np.uint64)
+    _check(lib.p2gpu_field_selftest(x.ctypes.data, y.ctypes.data, x.size, bad.ctypes.data))
+    return bad
 
 
 def hash_rows(rows):

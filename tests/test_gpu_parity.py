@@ -30,6 +30,34 @@ def _rand(shape, seed):
     return np.random.default_rng(seed).integers(0, P, size=shape, dtype=np.uint64)
 
 
+def test_field_primitives_match_portable_code(pkg, gpu):
+    """The device forms of canon / add / sub / reduce128 / mul / mul_add / x*2^e (e = 1..95) / Acc160 are
+    carry-chain inline assembly; the host, the verifier and the oracle run the portable code.  Every wrap
+    case: all pairs of an edge set around 0, 2^32, 2^63, p, 2^64 plus random words (any u64, not only
+    canonical ones: canon and reduce128 take arbitrary words)."""
+    eps = (1 << 32) - 1
+    pts = [0, 1, 2, eps - 1, eps, eps + 1, eps + 2, 1 << 33, (1 << 63) - 1, 1 << 63, (1 << 63) + 1,
+           P - eps - 1, P - eps, P - eps + 1, P - 2, P - 1, P, P + 1, P + eps - 2, P + eps - 1,
+           (1 << 64) - 2, (1 << 64) - 1, 0xFFFFFFFE00000000, 0xFFFFFFFEFFFFFFFF, 0x00000000FFFFFFFF,
+           0x0000000100000000, 0xFFFFFFFF, 0x8000000080000000, 0x7FFFFFFF7FFFFFFF]
+    for s in (1, 7, 12, 24, 31, 33, 36, 48, 60, 63):
+        pts += [(1 << s) - 1, 1 << s, (P - (1 << s)) % (1 << 64), ((1 << 64) - (1 << s))]
+    edge = np.array(sorted(set(pts)), dtype=np.uint64)
+    a = np.repeat(edge, edge.size)
+    b = np.tile(edge, edge.size)
+    rng = np.random.default_rng(5)
+    ra = rng.integers(0, 1 << 64, size=1 << 20, dtype=np.uint64)
+    rb = rng.integers(0, 1 << 64, size=1 << 20, dtype=np.uint64)
+    # random words with a sparse high or low half hit the carry corner cases far more often
+    ra[::3] &= np.uint64(0xFFFFFFFF00000000)
+    rb[1::3] |= np.uint64(0xFFFFFFFF00000000)
+    ra[2::5] |= np.uint64(0x00000000FFFFFFFF)
+    a = np.concatenate([a, ra, np.repeat(edge, 64)])
+    b = np.concatenate([b, rb, rng.integers(0, 1 << 64, size=64 * edge.size, dtype=np.uint64)])
+    bad = pkg.field_selftest(a, b)
+    assert not bad.any(), dict(zip("canon add sub reduce128 mul mul_add mul_pow2 acc160".split(), bad.tolist()))
+
+
 @pytest.mark.parametrize("d", [0, 1, 2, 5, 8, 11, 12, 13, 16])
 def test_ifft_and_lde_match_oracle(pkg, orc, gpu, d):
     # 12 = one LDS pass, 13 = first two-pass size, ragged column counts

@@ -142,6 +142,13 @@ constexpr int MAX_ROUNDS = 4;
 #ifndef NTT_TILE_BITS
 #define NTT_TILE_BITS 12
 #endif
+// elements a lane holds in the full-tile kernel = largest round radix.  16: radix-16 rounds, 256 lanes per tile,
+// ~100 VGPRs, 4 tiles (16 waves) per CU because of the 34 KB of LDS a tile needs.  8: radix-8 rounds, 512 lanes
+// per tile, the same LDS but twice the waves per CU to cover barriers and HBM latency
+#ifndef NTT_PER
+#define NTT_PER 8
+#endif
+#define NTT_THREADS ((1 << NTT_TILE_BITS) / NTT_PER)
 struct PassArgs {
   const gl_t *src;    // [cols][n] (or [cosets][cols][n])
   gl_t *dst;          // [cosets][cols][n]
@@ -312,7 +319,9 @@ __device__ __forceinline__ void do_round(gl_t *lds, const PassArgs &A, uint32_t 
     else round_regs<DIT, INV, L, false>(lds, A, TB, beta0, lo0, tw);       \
   } while (0)
   switch (logr) {
+#if NTT_PER == 16
   case 4: P2_ROUND(4); break;
+#endif
   case 3: P2_ROUND(3); break;
   case 2: P2_ROUND(2); break;
   default: P2_ROUND(1); break;
@@ -328,7 +337,7 @@ __device__ __forceinline__ void do_round(gl_t *lds, const PassArgs &A, uint32_t 
 #define NTT_MIN_WAVES 1
 #endif
 template <int DIT, bool INV, int TBC>
-__global__ __launch_bounds__(256, NTT_MIN_WAVES) void ntt_pass_kernel(PassArgs A) {
+__global__ __launch_bounds__(TBC ? NTT_THREADS : 256, NTT_MIN_WAVES) void ntt_pass_kernel(PassArgs A) {
   extern __shared__ gl_t lds[];
   const uint32_t TB = TBC ? TBC : A.a + A.tb;
   // XCD-aware block -> (tile, column, coset): the hardware deals consecutive block ids round-robin over
@@ -350,13 +359,13 @@ __global__ __launch_bounds__(256, NTT_MIN_WAVES) void ntt_pass_kernel(PassArgs A
   const uint32_t tsize = 1u << TB;
   // lane e + i * NT of the tile: when a contiguous run (2^tb elements) divides NT = 256, the global index is
   // linear in i (g0 + i * gstep) and so is the padded LDS index (l0 + i * 272): one add per access
-  constexpr int NT12 = 256;
-  const bool glin = A.tb <= 8;
+  constexpr int NT12 = NTT_THREADS;
+  const bool glin = (1u << A.tb) <= (uint32_t)NT12;
   const uint32_t g0 = gidx(threadIdx.x, hi_base, lo0, A.s, A.tb), gstep = (NT12 >> (glin ? A.tb : 0)) << A.s;
   const uint32_t l0 = pidx(threadIdx.x);
   if constexpr (TBC != 0) {
-    constexpr int PER = 16, NT = (1 << TBC) / PER;
-    static_assert(NT == NT12, "tile of 2^12 elements, 256 lanes");
+    constexpr int PER = NTT_PER, NT = (1 << TBC) / PER;
+    static_assert(NT == NT12, "full tile: NTT_THREADS lanes");
     gl_t x[PER];
     uint32_t g[PER];
 #pragma unroll
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(256, NTT_MIN_WAVES) void ntt_pass_kernel(PassArgs A
   }
   const bool post = A.post != 1;
   if constexpr (TBC != 0) {
-    constexpr int PER = 16, NT = (1 << TBC) / PER;
+    constexpr int PER = NTT_PER, NT = (1 << TBC) / PER;
     gl_t x[PER];
 #pragma unroll
     for (int i = 0; i < PER; i++) x[i] = lds[l0 + (uint32_t)i * (NT + NT / 16)];
@@ -440,15 +449,16 @@ __global__ void round_table_kernel(gl_t *out, gl_t root_n, uint32_t d, uint32_t 
 }
 
 static void split_rounds(uint32_t a, std::vector<uint32_t> &r) {
-  // rounds of 4 layers, remainder fixed up without ever using a lone 1 when avoidable
+  // rounds of LMAX layers (LMAX = log2 NTT_PER), remainder fixed up without ever using a lone 1 when avoidable
+  const uint32_t LMAX = NTT_PER == 16 ? 4 : 3;
   r.clear();
-  uint32_t q = a / 4, rem = a % 4;
-  if (rem == 1 && q >= 1) {  // 4 + 1 -> 3 + 2
-    for (uint32_t i = 0; i + 1 < q; i++) r.push_back(4);
-    r.push_back(3);
+  uint32_t q = a / LMAX, rem = a % LMAX;
+  if (rem == 1 && q >= 1 && LMAX >= 3) {  // L + 1 -> (L - 1) + 2
+    for (uint32_t i = 0; i + 1 < q; i++) r.push_back(LMAX);
+    r.push_back(LMAX - 1);
     r.push_back(2);
   } else {
-    for (uint32_t i = 0; i < q; i++) r.push_back(4);
+    for (uint32_t i = 0; i < q; i++) r.push_back(LMAX);
     if (rem) r.push_back(rem);
   }
 }
@@ -569,7 +579,7 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     const size_t lb = lds_bytes(TB);
 #define P2_LAUNCH(DITV, INVV)                                                                                \
   do {                                                                                                       \
-    if (TB == NTT_TILE_BITS) hipLaunchKernelGGL((ntt_pass_kernel<DITV, INVV, NTT_TILE_BITS>), grid, dim3((1u << NTT_TILE_BITS) / 16), lb, st, A);           \
+    if (TB == NTT_TILE_BITS) hipLaunchKernelGGL((ntt_pass_kernel<DITV, INVV, NTT_TILE_BITS>), grid, dim3(NTT_THREADS), lb, st, A);           \
     else hipLaunchKernelGGL((ntt_pass_kernel<DITV, INVV, 0>), grid, dim3(threads), lb, st, A);               \
   } while (0)
     if (plan->dit) {

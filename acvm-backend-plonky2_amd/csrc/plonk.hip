@@ -181,8 +181,12 @@ struct Consumer {
 // each evaluates its share of the gates (GateDesc.pad = group; group 0 also does the permutation
 // argument), so the tile's wires are pulled from HBM once per block instead of once per gate
 // (reuse distance ~120 KB per wave defeats L2 otherwise); partial sums meet in LDS.
+#ifndef P2_QUOT_WAVES
+#define P2_QUOT_WAVES 6  // waves per SIMD the register allocator must leave room for (80 VGPRs; 2-4 spilled): measured
+                         // 3.85 -> 3.27 ms (all gate kinds) and 0.83 -> 0.80 ms (sha mix) at 2^20 rows against no bound
+#endif
 template <bool POSEIDON, int G>
-__global__ __launch_bounds__(256) void quotient_kernel(const QuotArgs a) {
+__global__ __launch_bounds__(256, P2_QUOT_WAVES) void quotient_kernel(const QuotArgs a) {
   __shared__ gl_t red[2][G > 1 ? G : 1][G > 1 ? 64 : 1];
   const uint32_t grp = G > 1 ? threadIdx.y : 0;
   const uint32_t n = 1u << a.d;

@@ -271,6 +271,10 @@ void shard_assemble_cap(int world, unsigned rate_bits, size_t cap_per, const dig
 // blob header + gate table + (optional) cap + k_is -> the host-side fields of the handle; leaves
 // *off at the constants table.  Used by p2gpu_circuit_create and p2gpu_verifier_create.
 int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off, const uint8_t **cap_in);
+// per-kind parameter ranges of a gate-table entry (nullptr = acceptable) and its constraint count (hostcore.hip)
+const char *gate_validate(uint32_t kind, const uint32_t p[4], uint32_t W, uint32_t gate_consts, uint64_t *wires_used,
+                          uint32_t *consts_used);
+uint32_t gate_num_constraints(uint32_t kind, const uint32_t p[4]);
 // the verifier's plonk identity at zeta on the opened values (verify.hip); also the prover's self-check
 bool plonk_identity_holds(const p2gpu_circuit *c, const std::vector<ext_t> &op, const gl_t *betas, const gl_t *gammas,
                           const gl_t *alphas, ext_t zeta, const gl_t pih[4]);

@@ -51,7 +51,7 @@ void shard_assemble_cap(int world, unsigned rate_bits, size_t cap_per, const dig
 void (*g_circuit_release)(p2gpu_circuit *) = nullptr;
 }  // namespace p2
 
-namespace {
+namespace p2 {
 // Per-kind parameter ranges and wire/constant bounds of one gate-table entry.  Runs BEFORE anything
 // derives a size or an index from the parameters: the blob is untrusted input for the CPU-only
 // verifier (p2gpu_verifier_create) as much as for the prover, and the same descriptors drive the
@@ -134,9 +134,7 @@ uint32_t gate_num_constraints(uint32_t kind, const uint32_t p[4]) {
   }
   return 0;
 }
-}  // namespace
 
-namespace p2 {
 int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off_out, const uint8_t **cap_in) {
   if (len < 256) { set_err("blob too short"); return P2GPU_E_BLOB; }
   uint32_t h[64];

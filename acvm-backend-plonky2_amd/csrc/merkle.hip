@@ -126,8 +126,11 @@ __device__ __forceinline__ dig_t hash_or_noop(uint32_t nwords, F get, const gl_t
   return sponge_hash(nwords, get);
 }
 
+#ifndef P2_LEAF_WAVES
+#define P2_LEAF_WAVES 1
+#endif
 template <int H>
-__global__ __launch_bounds__(256) void hash_lde_leaves_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
+__global__ __launch_bounds__(256, P2_LEAF_WAVES) void hash_lde_leaves_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
                                                               dig_t *__restrict__ dig, const gl_t *__restrict__ prc) {
   const size_t n = (size_t)1 << d;
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -478,6 +478,255 @@ int emit(const Out &o, uint8_t *out, size_t *out_len) {
   return P2GPU_OK;
 }
 
+
+// ---- the reference's verifier-key file (second half) -----------------------------------------
+// `plonky2-backend write_vk` stores `verifier_data.to_bytes(&BackendGateSerializer)` (plonky2-backend/src/actions/
+// write_vk_action.rs:35-81) and `verify` reads it back with `VerifierCircuitData::from_bytes`
+// (noir_and_plonky2_serialization.rs:16-22).  The byte layout lives in the un-vendored crate (plonky2 0.2.2
+// util/serialization/mod.rs: write_verifier_only_circuit_data + write_common_circuit_data) and no VK file exists
+// in the reference tree: this is a restatement from recollection, **UNPINNED** -- nothing the reference produced
+// checks it; what IS pinned is the gate tag order (the list at write_vk_action.rs:39-61, tags count from 0) and
+// the bodies of the five custom gates (their `serialize` at add_many_u32.rs:94-97, arithmetic_u32.rs:93-95,
+// comparison.rs:104-108, range_check_u32.rs:59-61, subtraction_u32.rs:87-89).  Layout written / read here
+// (usize = u64 LE, bool = u8, field = canonical u64 LE, hash = 25 bytes for KeccakHash<25> / 32 for Poseidon):
+//   usize cap_height | hash cap[2^cap_height] | hash circuit_digest
+//   CircuitConfig: usize num_wires, num_routed_wires, num_constants, security_bits, num_challenges,
+//                  max_quotient_degree_factor | bool use_base_arithmetic_gate, zero_knowledge | FriConfig
+//   FriConfig: usize rate_bits, cap_height, num_query_rounds | u32 proof_of_work_bits |
+//              strategy: u8 0 Fixed(usizes) / 1 ConstantArityBits(usize, usize) / 2 MinSize(u8 flag [usize])
+//   FriParams: FriConfig | usizes reduction_arity_bits (len, items) | usize degree_bits | bool hiding
+//   SelectorsInfo: usizes selector_indices | usize #groups | (usize start, usize end) each
+//   usize quotient_degree_factor, num_gate_constraints, num_constants, num_public_inputs | usize #k_is | field k_is[]
+//   usize num_partial_products, num_lookup_polys, num_lookup_selectors | usize #luts (0)
+//   usize #gates | per gate: u32 tag | the gate's own serialize
+// The configuration constants the blob does not carry are those of CircuitConfig::wide_ecc_config
+// (circuit_translation/mod.rs:69 = standard_recursion_config with 234 / 80 wires): num_constants 2,
+// security_bits 100, max_quotient_degree_factor 8, use_base_arithmetic_gate, no zero knowledge,
+// ConstantArityBits(4, 5).
+struct VkGateTag {
+  uint32_t tag, kind, base;  // base: BaseSumGate<B>
+};
+const VkGateTag VK_TAGS[] = {{0, G_ARITHMETIC, 0},     {2, G_BASE_SUM, 2},        {3, G_BASE_SUM, 4},       {4, G_CONSTANT, 0},
+                             {10, G_NOOP, 0},          {12, G_POSEIDON, 0},       {13, G_PUBLIC_INPUT, 0},  {14, G_RANDOM_ACCESS, 0},
+                             {17, G_COMPARISON, 0},    {18, G_U32_ADD_MANY, 0},   {19, G_U32_ARITHMETIC, 0}, {20, G_U32_RANGE_CHECK, 0},
+                             {21, G_U32_SUBTRACTION, 0}};
+// Gate::degree() / num_constants() of the kinds the translators emit (gates/*.rs; the custom ones at
+// arithmetic_u32.rs:277-279, add_many_u32.rs:278-280, subtraction_u32.rs:222-224, range_check_u32.rs:168-170,
+// comparison.rs:325-327)
+void vk_gate_shape(uint32_t kind, const uint32_t p[4], uint32_t *degree, uint32_t *nconst) {
+  *nconst = 0;
+  switch (kind) {
+  case G_NOOP: *degree = 0; break;
+  case G_CONSTANT: *degree = 1; *nconst = p[0]; break;
+  case G_PUBLIC_INPUT: *degree = 1; break;
+  case G_ARITHMETIC: *degree = 3; *nconst = 2; break;
+  case G_BASE_SUM: *degree = p[0]; break;
+  case G_RANDOM_ACCESS: *degree = p[0] + 1; *nconst = p[2]; break;
+  case G_POSEIDON: *degree = 7; break;
+  case G_COMPARISON: *degree = 1u << ((p[0] + (p[1] ? p[1] : 1) - 1) / (p[1] ? p[1] : 1)); break;
+  default: *degree = 4; break;  // the four u32 gates: 1 << limb_bits, limb_bits = 2
+  }
+}
+
+struct VkOut : Out {
+  void usize(uint64_t x) { u64(x); }
+  void boolean(bool b) { u8(b ? 1 : 0); }
+};
+void vk_write_fri_config(VkOut &o, const p2gpu_circuit *c) {
+  o.usize(c->rate_bits); o.usize(c->cap_h); o.usize(c->num_queries); o.u32(c->pow_bits);
+  // ConstantArityBits(4, 5) when the steps are what that strategy yields for this degree, Fixed(steps) otherwise
+  std::vector<uint32_t> want;
+  {
+    uint32_t dbits = c->d;
+    while (dbits > 5 && dbits + c->rate_bits - 4 >= c->cap_h) { want.push_back(4); dbits -= 4; }
+  }
+  bool constant = want.size() == c->n_steps;
+  for (uint32_t i = 0; constant && i < c->n_steps; i++) constant = c->arity[i] == 4;
+  if (constant) { o.u8(1); o.usize(4); o.usize(5); }
+  else { o.u8(0); o.usize(c->n_steps); for (uint32_t i = 0; i < c->n_steps; i++) o.usize(c->arity[i]); }
+}
+int vk_write(const p2gpu_circuit *c, VkOut &o) {
+  if (c->cs.cap.size() != ((size_t)1 << c->cap_h)) { set_err("handle has no constants_sigmas cap"); return P2GPU_E_ARG; }
+  o.usize(c->cap_h);
+  for (auto &dg : c->cs.cap) o.dig(dg);
+  o.dig(c->circuit_digest);
+  o.usize(c->W); o.usize(c->R); o.usize(2); o.usize(100); o.usize(c->K); o.usize(8);
+  o.boolean(true); o.boolean(false);
+  vk_write_fri_config(o, c);
+  vk_write_fri_config(o, c);
+  o.usize(c->n_steps);
+  for (uint32_t i = 0; i < c->n_steps; i++) o.usize(c->arity[i]);
+  o.usize(c->d);
+  o.boolean(false);
+  o.usize(c->num_gates);
+  for (auto &G : c->gates) o.usize(G.sel_index);
+  {
+    std::vector<std::pair<uint32_t, uint32_t>> groups;
+    for (auto &G : c->gates)
+      if (groups.empty() || groups.back().first != G.group_start) groups.push_back({G.group_start, G.group_end});
+    o.usize(groups.size());
+    for (auto &g : groups) { o.usize(g.first); o.usize(g.second); }
+  }
+  o.usize(c->QF);
+  o.usize(c->max_gate_constraints);
+  o.usize(c->NC);
+  o.usize(c->num_pi);
+  o.usize(c->R);
+  for (auto k : c->k_is) o.u64(k);
+  o.usize(c->PP); o.usize(0); o.usize(0); o.usize(0);
+  o.usize(c->num_gates);
+  for (auto &G : c->gates) {
+    const VkGateTag *t = nullptr;
+    for (auto &e : VK_TAGS)
+      if (e.kind == G.kind && (G.kind != G_BASE_SUM || e.base == G.p[0])) t = &e;
+    if (!t) { set_err("gate kind %u (BaseSum base %u) is not in the reference's BackendGateSerializer", G.kind, G.p[0]); return P2GPU_E_ARG; }
+    o.u32(t->tag);
+    switch (G.kind) {
+    case G_ARITHMETIC: case G_CONSTANT: case G_U32_ARITHMETIC: case G_U32_SUBTRACTION: case G_U32_RANGE_CHECK: o.usize(G.p[0]); break;
+    case G_BASE_SUM: o.usize(G.p[1]); break;
+    case G_RANDOM_ACCESS: o.usize(G.p[0]); o.usize(G.p[1]); o.usize(G.p[2]); break;
+    case G_U32_ADD_MANY: case G_COMPARISON: o.usize(G.p[0]); o.usize(G.p[1]); break;
+    default: break;  // NoopGate, PoseidonGate, PublicInputGate: empty bodies
+    }
+  }
+  return P2GPU_OK;
+}
+
+struct VkIn : Cursor {
+  uint64_t usize(uint64_t max) {
+    const uint64_t v = u64();
+    if (v > max) ok = false;
+    return ok ? v : 0;
+  }
+  uint32_t u32() {
+    uint32_t v = 0;
+    if (const uint8_t *q = take(4)) memcpy(&v, q, 4);
+    return v;
+  }
+  int boolean() {
+    const uint8_t *q = take(1);
+    if (q && *q > 1) ok = false;
+    return q ? *q : 0;
+  }
+};
+struct VkFri {
+  uint32_t rate_bits, cap_h, queries, pow_bits;
+};
+bool vk_read_fri_config(VkIn &in, VkFri &f) {
+  f.rate_bits = (uint32_t)in.usize(3); f.cap_h = (uint32_t)in.usize(32); f.queries = (uint32_t)in.usize(64); f.pow_bits = in.u32();
+  const uint8_t *tag = in.take(1);
+  if (!tag) return false;
+  if (*tag == 0) { const uint64_t n = in.usize(8); for (uint64_t i = 0; i < n; i++) in.usize(MAX_ARITY_BITS); }
+  else if (*tag == 1) { in.usize(MAX_ARITY_BITS); in.usize(32); }
+  else if (*tag == 2) { const uint8_t *some = in.take(1); if (some && *some == 1) in.usize(1u << 24); else if (!some || *some > 1) in.ok = false; }
+  else in.ok = false;
+  return in.ok;
+}
+// plonky2 VK bytes -> the verifier blob of p2gpu_verifier_create (header | gate table | cap | k_is, flags 0b11)
+int vk_read(const uint8_t *bytes, size_t len, int hasher, Out &blob) {
+  VkIn in;
+  in.p = bytes; in.len = len;
+  const size_t hb = hasher ? 32 : 25;
+  auto fail = [](const char *what) { set_err("malformed verifier key: %s", what); return P2GPU_E_BLOB; };
+  const uint32_t cap_h = (uint32_t)in.usize(16);
+  if (!in.ok) return fail("cap height");
+  const uint8_t *cap = in.take(hb << cap_h);
+  const uint8_t *digest = in.take(hb);
+  if (!cap || !digest) return fail("truncated (cap / digest)");
+  uint32_t h[64];
+  memset(h, 0, sizeof h);
+  h[0] = 0x43473250u; h[1] = 1;
+  h[3] = (uint32_t)in.usize(4096); h[4] = (uint32_t)in.usize(MAX_ROUTED);
+  in.usize(4096);  // config.num_constants
+  in.usize(1024);  // security_bits
+  h[7] = (uint32_t)in.usize(MAX_CHALLENGES);
+  in.usize(64);    // max_quotient_degree_factor
+  in.boolean();
+  if (in.boolean()) return fail("zero-knowledge circuits are not supported");
+  VkFri f0, f1;
+  if (!vk_read_fri_config(in, f0) || !vk_read_fri_config(in, f1)) return fail("FRI configuration");
+  if (f0.rate_bits != f1.rate_bits || f0.cap_h != f1.cap_h || f0.queries != f1.queries || f0.pow_bits != f1.pow_bits || f0.cap_h != cap_h)
+    return fail("CircuitConfig.fri_config and FriParams.config disagree");
+  h[9] = f0.rate_bits; h[10] = f0.cap_h; h[11] = f0.pow_bits; h[12] = f0.queries;
+  const uint32_t n_steps = (uint32_t)in.usize(8);
+  h[13] = n_steps;
+  for (uint32_t i = 0; i < n_steps; i++) h[14 + i] = (uint32_t)in.usize(MAX_ARITY_BITS);
+  h[2] = (uint32_t)in.usize(24);
+  if (in.boolean()) return fail("hiding FRI is not supported");
+  h[22] = (uint32_t)hasher;
+  const uint32_t nsel = (uint32_t)in.usize(MAX_GATES);
+  if (!in.ok) return fail("header fields out of range");
+  std::vector<uint32_t> sel(nsel);
+  for (auto &x : sel) x = (uint32_t)in.usize(4096);
+  const uint32_t ngroups = (uint32_t)in.usize(MAX_GATES);
+  std::vector<std::pair<uint32_t, uint32_t>> groups(in.ok ? ngroups : 0);
+  for (auto &g : groups) { g.first = (uint32_t)in.usize(MAX_GATES); g.second = (uint32_t)in.usize(MAX_GATES); }
+  h[8] = (uint32_t)in.usize(64);
+  const uint32_t num_gate_constraints = (uint32_t)in.usize(MAX_GATE_CONSTRAINTS);
+  h[5] = (uint32_t)in.usize(4096);
+  h[24] = (uint32_t)in.usize(1u << 20);
+  const uint32_t nk = (uint32_t)in.usize(MAX_ROUTED);
+  if (!in.ok || nk != h[4]) return fail("selectors / k_is");
+  std::vector<gl_t> k_is(nk);
+  for (auto &k : k_is) k = in.felt();
+  h[26] = (uint32_t)in.usize(64);
+  if (in.usize(0) || in.usize(0) || in.usize(0) || !in.ok) return fail("lookup tables are not supported");
+  const uint32_t ngates = (uint32_t)in.usize(MAX_GATES);
+  if (!in.ok || ngates != nsel || ngates == 0) return fail("gate count");
+  h[23] = ngates;
+  h[6] = 0;
+  for (auto x : sel) h[6] = std::max(h[6], x + 1);  // selector columns come first in the constants table
+  h[25] = 3;
+  memcpy(&h[32], digest, hb);
+  blob.put(h, sizeof h);
+  uint32_t max_c = 0;
+  for (uint32_t i = 0; i < ngates; i++) {
+    const uint32_t tag = in.u32();
+    const VkGateTag *t = nullptr;
+    for (auto &e : VK_TAGS)
+      if (e.tag == tag) t = &e;
+    if (!in.ok || !t) return fail("gate tag outside the kinds the translators emit");
+    uint32_t g[12];
+    memset(g, 0, sizeof g);
+    g[0] = t->kind;
+    switch (t->kind) {
+    case G_ARITHMETIC: case G_CONSTANT: case G_U32_ARITHMETIC: case G_U32_SUBTRACTION: case G_U32_RANGE_CHECK: g[1] = (uint32_t)in.usize(4096); break;
+    case G_BASE_SUM: g[1] = t->base; g[2] = (uint32_t)in.usize(64); break;
+    case G_RANDOM_ACCESS: g[1] = (uint32_t)in.usize(6); g[2] = (uint32_t)in.usize(1024); g[3] = (uint32_t)in.usize(2); break;
+    case G_U32_ADD_MANY: case G_COMPARISON: g[1] = (uint32_t)in.usize(1024); g[2] = (uint32_t)in.usize(1024); break;
+    default: break;
+    }
+    if (!in.ok) return fail("gate parameters");
+    g[5] = sel[i];
+    g[6] = g[7] = 0;
+    for (auto &gr : groups)
+      if (gr.first <= i && i < gr.second) { g[6] = gr.first; g[7] = gr.second; }
+    // constraint count, degree and constant count follow from the kind; circuit_parse re-validates all of it
+    {
+      uint64_t wu = 0;
+      uint32_t cu = 0;
+      if (h[5] < h[6]) return fail("fewer constant columns than selectors");
+      if (const char *why = gate_validate(g[0], &g[1], h[3], h[5] - h[6], &wu, &cu)) return fail(why);
+    }
+    uint32_t deg, nconst;
+    vk_gate_shape(g[0], &g[1], &deg, &nconst);
+    g[9] = deg; g[10] = nconst;
+    g[8] = gate_num_constraints(g[0], &g[1]);
+    max_c = std::max(max_c, g[8]);
+    blob.put(g, sizeof g);
+  }
+  if (in.at != in.len) return fail("trailing bytes");
+  if (max_c != num_gate_constraints) return fail("num_gate_constraints does not match the gate set");
+  for (size_t i = 0; i < ((size_t)1 << cap_h); i++) {
+    uint8_t e[32];
+    memset(e, 0, sizeof e);
+    memcpy(e, cap + hb * i, hb);
+    blob.put(e, 32);
+  }
+  blob.put(k_is.data(), 8 * k_is.size());
+  return P2GPU_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -510,6 +759,22 @@ int p2gpu_verify_compressed(const p2gpu_circuit *c, const uint8_t *cproof, size_
   Out o;
   write_uncompressed(P, o);
   return p2gpu_verify(c, o.v.data(), o.v.size());
+} P2GPU_CATCH
+
+// ---- verifier key in the reference's file format (UNPINNED restatement, see vk_write above) ----
+int p2gpu_circuit_export_vk_plonky2(const p2gpu_circuit *c, uint8_t *out, size_t *out_len) try {
+  if (!c || !out_len) return P2GPU_E_ARG;
+  use_hasher(c);
+  VkOut o;
+  if (int rc = vk_write(c, o)) return rc;
+  return emit(o, out, out_len);
+} P2GPU_CATCH
+
+int p2gpu_verifier_create_plonky2(const uint8_t *vk, size_t len, int hasher, p2gpu_circuit **out) try {
+  if (!vk || !out || hasher < 0 || hasher > 1) return P2GPU_E_ARG;
+  Out blob;
+  if (int rc = vk_read(vk, len, hasher, blob)) return rc;
+  return p2gpu_verifier_create(blob.v.data(), blob.v.size(), out);
 } P2GPU_CATCH
 
 }  // extern "C"

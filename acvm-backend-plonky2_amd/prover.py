@@ -92,6 +92,8 @@ def load_library():
     lib.p2gpu_fill_witness.argtypes = [vp, vp]
     lib.p2gpu_verify.argtypes = [vp, u8p, sz]
     lib.p2gpu_circuit_export_vk.argtypes = [vp, u8p, ctypes.POINTER(sz)]
+    lib.p2gpu_circuit_export_vk_plonky2.argtypes = [vp, u8p, ctypes.POINTER(sz)]
+    lib.p2gpu_verifier_create_plonky2.argtypes = [u8p, sz, ctypes.c_int, ctypes.POINTER(vp)]
     lib.p2gpu_verifier_create.argtypes = [u8p, sz, ctypes.POINTER(vp)]
     lib.p2gpu_proof_compress.argtypes = [vp, u8p, sz, u8p, ctypes.POINTER(sz)]
     lib.p2gpu_proof_decompress.argtypes = [vp, u8p, sz, u8p, ctypes.POINTER(sz)]
@@ -372,11 +374,21 @@ class _ProofFormats:
         buf = np.frombuffer(bytes(compressed), dtype=np.uint8)
         _check(self._lib.p2gpu_verify_compressed(self._h, buf.ctypes.data if buf.size else None, buf.size))
 
+    def to_plonky2_bytes(self):
+        """``verifier_data.to_bytes(&BackendGateSerializer)``: the VK file `write_vk` stores
+        (write_vk_action.rs:77-80).  UNPINNED restatement of plonky2's serialization (include/p2gpu.h)."""
+        n = ctypes.c_size_t(0)
+        _check(self._lib.p2gpu_circuit_export_vk_plonky2(self._h, None, ctypes.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        _check(self._lib.p2gpu_circuit_export_vk_plonky2(self._h, out.ctypes.data, ctypes.byref(n)))
+        return out[:n.value].tobytes()
+
 
 # the prover handle offers the same three conversions
 CircuitData.compress = _ProofFormats.compress
 CircuitData.decompress = _ProofFormats.decompress
 CircuitData.verify_compressed = _ProofFormats.verify_compressed
+CircuitData.to_plonky2_vk_bytes = _ProofFormats.to_plonky2_bytes
 
 
 class VerifierCircuitData(_ProofFormats):
@@ -389,6 +401,26 @@ class VerifierCircuitData(_ProofFormats):
         self._blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8))
         self._h = ctypes.c_void_p()
         _check(lib.p2gpu_verifier_create(self._blob.ctypes.data, self._blob.nbytes, ctypes.byref(self._h)))
+        self._read_header()
+
+    @classmethod
+    def from_plonky2_bytes(cls, vk, hasher=0):
+        """``VerifierCircuitData::from_bytes(buffer, &BackendGateSerializer)`` of the reference's verify action
+        (noir_and_plonky2_serialization.rs:16-22).  UNPINNED restatement of plonky2's serialization."""
+        self = cls.__new__(cls)
+        lib = load_library()
+        self._lib = lib
+        buf = np.ascontiguousarray(np.frombuffer(bytes(vk), dtype=np.uint8))
+        self._h = ctypes.c_void_p()
+        _check(lib.p2gpu_verifier_create_plonky2(buf.ctypes.data if buf.size else None, buf.size, int(hasher), ctypes.byref(self._h)))
+        n = ctypes.c_size_t(0)
+        _check(lib.p2gpu_circuit_export_vk(self._h, None, ctypes.byref(n)))
+        self._blob = np.zeros(n.value, dtype=np.uint8)
+        _check(lib.p2gpu_circuit_export_vk(self._h, self._blob.ctypes.data, ctypes.byref(n)))
+        self._read_header()
+        return self
+
+    def _read_header(self):
         hdr = self._blob[:256].view(np.uint32)
         self.degree_bits = int(hdr[2])
         self.cap_height = int(hdr[10])

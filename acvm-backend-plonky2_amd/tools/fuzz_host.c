@@ -121,11 +121,33 @@ int main(int argc, char **argv) {
   uint32_t ng;
   memcpy(&ng, blob + 4 * 23, 4);
   const size_t blob_prefix = 256 + 48 * (size_t)(ng < 64 ? ng : 64);
-  long blobs_ok = 0, blobs_rejected = 0, proofs_rejected = 0, unchanged = 0, accepted_mutants = 0;
+  long blobs_ok = 0, blobs_rejected = 0, proofs_rejected = 0, unchanged = 0, accepted_mutants = 0, vks_ok = 0, vks_rejected = 0;
+  /* the same key in the reference's VK file format (p2gpu_verifier_create_plonky2) */
+  size_t vk_len = 0;
+  (void)p2gpu_circuit_export_vk_plonky2(good, NULL, &vk_len);
+  uint8_t *vk = malloc(vk_len + 1);
+  if (p2gpu_circuit_export_vk_plonky2(good, vk, &vk_len)) {
+    fprintf(stderr, "export_vk_plonky2 failed: %s\n", p2gpu_last_error());
+    return 2;
+  }
   for (long it = 0; it < iters; it++) {
-    const unsigned target = (unsigned)(rnd() % 3);
+    const unsigned target = (unsigned)(rnd() % 4);
     size_t n;
-    if (target == 0) {
+    if (target == 3) {
+      uint8_t *m = mutate(vk, vk_len, &n, vk_len);
+      p2gpu_circuit *h = NULL;
+      if (p2gpu_verifier_create_plonky2(m, n, 0, &h) == 0) {
+        vks_ok++;
+        size_t ol = 0;
+        (void)p2gpu_verify(h, proof, proof_len);
+        (void)p2gpu_verify_compressed(h, comp, comp_len);
+        (void)p2gpu_circuit_export_vk_plonky2(h, NULL, &ol);
+        p2gpu_circuit_destroy(h);
+      } else {
+        vks_rejected++;
+      }
+      free(m);
+    } else if (target == 0) {
       uint8_t *m = mutate(blob, blob_len, &n, blob_prefix);
       p2gpu_circuit *h = NULL;
       if (p2gpu_verifier_create(m, n, &h) == 0) {
@@ -166,8 +188,9 @@ int main(int argc, char **argv) {
       free(m);
     }
   }
-  printf("iterations %ld: mutated blobs parsed %ld / rejected %ld, mutated proofs rejected %ld, no-op mutations %ld, ACCEPTED MUTANTS %ld\n",
-         iters, blobs_ok, blobs_rejected, proofs_rejected, unchanged, accepted_mutants);
+  printf("iterations %ld: mutated blobs parsed %ld / rejected %ld, mutated VK files parsed %ld / rejected %ld, mutated proofs rejected %ld, no-op mutations %ld, ACCEPTED MUTANTS %ld\n",
+         iters, blobs_ok, blobs_rejected, vks_ok, vks_rejected, proofs_rejected, unchanged, accepted_mutants);
+  free(vk);
   p2gpu_circuit_destroy(good);
   free(out);
   free(blob);

@@ -82,10 +82,12 @@ int main(int argc, char **argv) {
   }
   if (vk_path) {
     size_t vk_len = 0;
-    p2gpu_circuit_export_vk(c, NULL, &vk_len);
+    /* with --reference-format the key goes out as the reference's VK file too (UNPINNED layout, include/p2gpu.h) */
+    int (*export_vk)(const p2gpu_circuit *, uint8_t *, size_t *) = ref_format ? p2gpu_circuit_export_vk_plonky2 : p2gpu_circuit_export_vk;
+    export_vk(c, NULL, &vk_len);
     uint8_t *vk = malloc(vk_len);
     FILE *vf = fopen(vk_path, "wb");
-    if (!vk || p2gpu_circuit_export_vk(c, vk, &vk_len) || !vf || fwrite(vk, 1, vk_len, vf) != vk_len) {
+    if (!vk || export_vk(c, vk, &vk_len) || !vf || fwrite(vk, 1, vk_len, vf) != vk_len) {
       fprintf(stderr, "cannot write %s\n", vk_path);
       return 1;
     }

@@ -46,7 +46,10 @@ int main(int argc, char **argv) {
     return 1;
   }
   p2gpu_circuit *c = NULL;
-  int rc = p2gpu_verifier_create(vk, vk_len, &c);
+  /* "P2GC": this library's verifier blob; anything else is read as the reference's VK file
+   * (VerifierCircuitData::to_bytes through BackendGateSerializer, KeccakGoldilocksConfig) */
+  const int own = vk_len >= 4 && vk[0] == 0x50 && vk[1] == 0x32 && vk[2] == 0x47 && vk[3] == 0x43;
+  int rc = own ? p2gpu_verifier_create(vk, vk_len, &c) : p2gpu_verifier_create_plonky2(vk, vk_len, 0, &c);
   if (rc) {
     fprintf(stderr, "p2gpu_verifier_create: %d: %s\n", rc, p2gpu_last_error());
     return 2;

@@ -166,6 +166,16 @@ int p2gpu_circuit_export_vk(const p2gpu_circuit *c, uint8_t *out, size_t *len);
 /* Handle from such a blob (a full circuit blob with flags 0b11 works too: only its prefix is read).
  * No device is touched; the prove / fill / shard entry points reject it with P2GPU_E_ARG. */
 int p2gpu_verifier_create(const uint8_t *blob, size_t len, p2gpu_circuit **out);
+/* The same verifier key in the reference's own file format: `VerifierCircuitData::to_bytes(&BackendGateSerializer)`
+ * as `write_vk` stores it (plonky2-backend/src/actions/write_vk_action.rs:65-81) and `verify` reads it
+ * (noir_and_plonky2_serialization.rs:16-22).  UNPINNED: the layout is plonky2 0.2.2's util/serialization (a crate
+ * that is not in the reference tree) restated from recollection -- no VK file exists there to check it against;
+ * only the gate tag order (write_vk_action.rs:39-61) and the custom gates' bodies are taken from reference
+ * source.  Exact inverse pair: create_plonky2(export_plonky2(c)) verifies what c verifies.
+ * hasher: 0 = KeccakGoldilocksConfig (the reference), 1 = PoseidonGoldilocksConfig (the digest width is not
+ * in the bytes).  out == NULL: only report the size in *len. */
+int p2gpu_circuit_export_vk_plonky2(const p2gpu_circuit *c, uint8_t *out, size_t *len);
+int p2gpu_verifier_create_plonky2(const uint8_t *vk, size_t len, int hasher, p2gpu_circuit **out);
 
 /* ---- the reference's on-disk proof format (host code only) ------------------------------------
  * `plonky2-backend prove` writes hex(proof.compress(..).to_bytes()) (prove_action.rs:38-42,75-78) and

@@ -339,13 +339,17 @@ def test_standalone_c_caller(pkg, orc, gpu, tmp_path):
     r = subprocess.run([vexe, str(tmp_path / "vk.blob"), str(tmp_path / "bad.bin")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 3 and "rejected" in r.stderr
     # --reference-format: hex of the compressed proof, the file format of the reference's CLI
-    cmd = [exe, str(tmp_path / "c.blob"), str(tmp_path / "w.bin"), str(tmp_path / "p.hex"), str(tmp_path / "pi.bin"), "--reference-format"]
+    # (+ --vk: the key in the reference's VK file layout, which p2gpu-verify tells from its own blob by the magic)
+    cmd = [exe, str(tmp_path / "c.blob"), str(tmp_path / "w.bin"), str(tmp_path / "p.hex"), str(tmp_path / "pi.bin"), "--reference-format",
+           "--vk", str(tmp_path / "vk.ref")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     hx = (tmp_path / "p.hex").read_text()
     assert len(hx) // 2 < len(expect) and bytes.fromhex(hx)[:25] == expect[:25]
-    r = subprocess.run([vexe, str(tmp_path / "vk.blob"), str(tmp_path / "p.hex")], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 0 and "accepted" in r.stderr, r.stderr
+    assert (tmp_path / "vk.ref").read_bytes()[:8] == (4).to_bytes(8, "little")  # usize cap_height first
+    for key in ("vk.blob", "vk.ref"):
+        r = subprocess.run([vexe, str(tmp_path / key), str(tmp_path / "p.hex")], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and "accepted" in r.stderr, r.stderr
     # a broken blob is reported through the error code + message, not a crash
     (tmp_path / "bad.blob").write_bytes(b"\0" * 300)
     r = subprocess.run([exe, str(tmp_path / "bad.blob"), str(tmp_path / "w.bin"), str(tmp_path / "p3.bin")],

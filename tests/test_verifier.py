@@ -220,3 +220,52 @@ def test_poseidon_hasher_oracle_prover_vs_product_verifier(pkg, orc, d, mix, npi
     ock, vdk, _, _ = make(pkg, orc, d, mix, 9, npi, hasher=0)
     with pytest.raises(pkg.P2GpuError):
         vdk.verify(proof)
+
+
+@pytest.mark.parametrize("d,mix,seed,npi,nw,hasher", [
+    (5, "arith", 1, 0, 234, 0),
+    (8, "ecdsa", 3, 0, 234, 0),     # all twelve gate kinds minus the public-input pair
+    (9, "ecdsa", 4, 4, 234, 0),     # + PoseidonGate / PublicInputGate, two selector groups
+    (7, "arith", 5, 1, 135, 0),
+    (10, "sha", 6, 0, 234, 0),
+    (8, "sha", 9, 0, 234, 1),       # PoseidonGoldilocksConfig: 32-byte digests
+])
+def test_reference_vk_file_format_round_trip(pkg, orc, d, mix, seed, npi, nw, hasher):
+    """`write_vk` / `verify` of the reference exchange `VerifierCircuitData::to_bytes(&BackendGateSerializer)`
+    (write_vk_action.rs:77-80, noir_and_plonky2_serialization.rs:16-22).  The restatement is UNPINNED (no VK file
+    in the reference tree); what is tested: export -> import is lossless (same verifier blob, same bytes again),
+    the imported key accepts the oracle's proof and rejects a tampered one, the layout's fixed points (cap height,
+    cap, digest, wide_ecc_config constants, gate tags of write_vk_action.rs:39-61) sit where the layout says."""
+    oc, vd, wires, pis = make(pkg, orc, d, mix, seed, npi, nw, hasher=hasher)
+    proof, _ = oc.prove(wires, public_inputs=pis)
+    vk = vd.to_plonky2_bytes()
+    vd2 = pkg.VerifierCircuitData.from_plonky2_bytes(vk, hasher=hasher)
+    assert vd2.to_bytes() == vd.to_bytes()
+    assert vd2.to_plonky2_bytes() == vk
+    vd2.verify(proof)
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 4
+    with pytest.raises(pkg.P2GpuError):
+        vd2.verify(bytes(bad))
+    hb = 32 if hasher else 25
+    u64 = lambda off: int.from_bytes(vk[off:off + 8], "little")
+    assert u64(0) == 4 and vk[8:8 + 16 * hb] == oc.cap() and vk[8 + 16 * hb:8 + 17 * hb] == oc.digest()
+    cfg = 8 + 17 * hb
+    assert [u64(cfg + 8 * i) for i in range(6)] == [nw, 80, 2, 100, 2, 8] and vk[cfg + 48:cfg + 50] == b"\x01\x00"
+    # FriConfig: rate_bits 3, cap_height 4, 28 queries, 16 PoW bits, ConstantArityBits(4, 5)
+    fri = cfg + 50
+    assert [u64(fri), u64(fri + 8), u64(fri + 16)] == [3, 4, 28] and vk[fri + 24:fri + 28] == (16).to_bytes(4, "little")
+    assert vk[fri + 28] == 1 and [u64(fri + 29), u64(fri + 37)] == [4, 5]
+    # truncations and bit flips never crash the reader: rejected, or parsed into some key (configuration words the
+    # blob does not keep, e.g. security_bits, may change without changing the key)
+    rng = np.random.default_rng(seed)
+    for cut in [0, 7, 8, cfg, fri + 10, len(vk) - 1]:
+        with pytest.raises(pkg.P2GpuError):
+            pkg.VerifierCircuitData.from_plonky2_bytes(vk[:cut], hasher=hasher)
+    for _ in range(60):
+        m = bytearray(vk)
+        m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            pkg.VerifierCircuitData.from_plonky2_bytes(bytes(m), hasher=hasher).close()
+        except pkg.P2GpuError:
+            continue

@@ -28,3 +28,4 @@ from .prover import (  # noqa: F401
 from .synth import make_circuit, synth_lib_path  # noqa: F401
 from . import parallel  # noqa: F401,E402
 from . import translate  # noqa: F401,E402
+from . import acir  # noqa: F401,E402

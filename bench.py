@@ -7,11 +7,20 @@ bytes back on the host (the boundary of p2gpu_prove_dev).  N > 1: one process pe
 (torch.distributed / RCCL), every rank proves its own independent proofs (replicas, weak
 scaling, no data-path collective); time = max over ranks between two barriers.
 
+BASELINE.json's metric has two halves and the line carries both: `value` = proofs/sec, the throughput of
+a proving service that keeps --in-flight proofs (default 4; separate circuit handles / HIP streams, one
+host thread each) in flight per GPU, K steps = K proofs, ms_per_step = wall time / K; and
+`latency_ms_single_proof` = the prove latency, measured in its own pass with exactly one proof on the GPU
+at a time (`single_proof` also gives that pass's proofs/sec -- the round-1 headline).  A lone proof leaves
+the GPU idle at its eleven Fiat-Shamir sync points and under-filled in the top levels of every Merkle tree
+(one dependent Keccak-f per level); other proofs' kernels fill those holes.
+
 The timed region runs the production path only: no per-launch events, no oracle.  After it, in
 the same process, separate passes collect what the JSON line reports beside `value`:
+  * `single_proof`: one proof at a time (latency);
   * `host_witness`: the same proofs through p2gpu_prove (witness in host RAM, the 245 MB H2D inside
     the call) -- SURVEY.md 8(d)'s boundary-to-boundary number, never `value`;
-  * `pipelined`: three proofs in flight on one GPU (separate handles / streams);
+  * `pipelined` (only with --in-flight 1): three proofs in flight on one GPU;
   * `roofline` + `kernel_ms_per_proof`: per-launch HIP events on the library's launch stream
     (`profile` knob) over a few extra proofs;
   * `cpu_baseline` (N = 1): the oracle = CPU port, on THIS workload, all host cores, unscaled.
@@ -156,8 +165,8 @@ def cpu_baseline(pkg, d, mix, n_pi, single_thread_bits):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--degree-bits", type=int, default=17)
     ap.add_argument("--mix", default="sha")
     ap.add_argument("--workload", choices=["synth", "sha256"], default="synth",
@@ -171,9 +180,11 @@ def main():
     ap.add_argument("--public-inputs", type=int, default=0,
                     help="public inputs of the synthetic circuit (> 0 adds PoseidonGate rows to the circuit and the "
                          "PoseidonGate to the gate set every LDE row evaluates); 0 = the BASELINE parity shape")
-    ap.add_argument("--in-flight", type=int, default=1,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="independent proofs in flight per GPU IN THE TIMED REGION (separate circuit handles / HIP streams, "
-                         "one host thread each); 1 = strictly one proof at a time, so ms_per_step is a prove latency")
+                         "one host thread each; measured on MI355X at 2^20 rows: 1 -> 129, 2 -> 143, 3 -> 156, 4 -> 159, 6 -> 148 "
+                         "proofs/s); 1 = strictly one proof at a time, so ms_per_step is a prove latency.  Capped so that the "
+                         "handles fit HBM (2^23 rows: 2, 2^24 rows: 1); the prove latency is measured in its own pass either way")
     ap.add_argument("--pipelined", type=int, default=3,
                     help="N = 1: after the timed region, also measure this many proofs in flight (0 = skip)")
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
@@ -247,7 +258,7 @@ def main():
                                 hasher=1 if args.hasher == "poseidon" else 0)
         blob, wires = made[0], made[1]
         pis = made[2] if args.public_inputs else ()
-    S = 1 if sharded else max(1, min(args.in_flight, args.steps))
+    S = 1 if sharded else max(1, min(args.in_flight, args.steps, 1 if d >= 21 else (2 if d == 20 else 8)))
     cds = [pkg.CircuitData(blob) for _ in range(S)]
     if args.mode == "sharded":
         # world 1: same code path as a replica (nothing to exchange); world > 1: RCCL inside the library
@@ -302,7 +313,7 @@ def main():
 
     if args.timed_only:
         if rank == 0:
-            print(json.dumps({"metric": f"proofs/sec at 2^{d + 3} LDE rows (prove latency = ms_per_step)", "value": (args.steps if sharded else world * args.steps) / dt,
+            print(json.dumps({"metric": f"proofs/sec at 2^{d + 3} LDE rows, {S} proof(s) in flight per GPU", "value": (args.steps if sharded else world * args.steps) / dt,
                               "unit": "proofs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                               "proofs_in_process": args.steps + max(args.warmup, S), "timed_only": True}), flush=True)
         for c_ in cds:
@@ -314,6 +325,17 @@ def main():
 
     # ---- separate passes (not part of `value`) ----
     cd = cds[0]
+    # (0) prove latency: exactly one proof on the GPU at a time (same handle, same resident witness)
+    if S == 1:
+        single_ms = dt / args.steps * 1e3
+    else:
+        nlat = max(3, min(args.steps, 8))
+        run([cd], 1)
+        barrier()
+        t1 = time.perf_counter()
+        run([cd], nlat)
+        barrier()
+        single_ms = pkg.parallel.max_over_ranks(time.perf_counter() - t1) / nlat * 1e3
     # (a) per-launch HIP events on the library's launch stream -> roofline of the dominant kernel
     cd.set("profile", 1)
     P = max(1, args.profile_steps)
@@ -366,7 +388,7 @@ def main():
         gbps_impl = impl_per_launch / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(name)
         out = {
-            "metric": f"proofs/sec at 2^{d + 3} LDE rows (prove latency = ms_per_step)",
+            "metric": f"proofs/sec at 2^{d + 3} LDE rows, {S} proof(s) in flight per GPU (prove latency of a lone proof: latency_ms_single_proof)",
             "value": total_proofs / dt,
             "unit": "proofs/sec",
             "n_gpus": world,
@@ -407,12 +429,16 @@ def main():
                                                 f"/ launches of that step per proof",
                 "implementation_bytes_per_launch": impl_per_launch,
                 "frac_traffic": (traffic / (avg_ms * 1e-3) / 1e9 if traffic else gbps_impl) / HBM_PEAK_GBPS,
-                "whole_proof": {"algorithmic_bytes": total_b, "achieved": total_b / (ms_step * 1e-3) / 1e9, "unit": "GB/s",
-                                "frac": total_b / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                "note": "B(N) / t_prove of SURVEY.md 8(d); the prover is VALU-issue-bound, see `issue`"},
+                "whole_proof": {"algorithmic_bytes": total_b, "achieved": total_b / (single_ms * 1e-3) / 1e9, "unit": "GB/s",
+                                "frac": total_b / (single_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                "note": "B(N) / t_prove of SURVEY.md 8(d) with t_prove = latency_ms_single_proof; the prover is "
+                                        "VALU-issue-bound, see `issue`",
+                                "frac_at_throughput": total_b * (total_proofs / world / dt) / 1e9 / HBM_PEAK_GBPS},
                 "issue": issue_roofline(name, 1e3 / avg_ms),
             },
-            "latency_ms_single_proof": ms_step if S == 1 else None,
+            "latency_ms_single_proof": single_ms,
+            "single_proof": {"in_flight": 1, "ms_per_proof": single_ms, "proofs_per_sec": (1 if sharded else world) * 1e3 / single_ms,
+                             "note": "one proof on the GPU at a time (the round-1 headline configuration)"},
             "in_flight_per_gpu": S,
             "host_witness": host,
             "pipelined": pipe,

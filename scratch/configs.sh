@@ -5,13 +5,13 @@ python bench.py > gpurun_out/r02_cfg/bench.json 2> gpurun_out/r02_cfg/bench.err
 python bench.py --public-inputs 4 --no-cpu-baseline > gpurun_out/r02_cfg/bench_pi4.json 2>/dev/null
 python bench.py --mix ecdsa --no-cpu-baseline > gpurun_out/r02_cfg/bench_d17_ecdsa.json 2>/dev/null
 python bench.py --degree-bits 13 --mix arith --no-cpu-baseline --steps 30 > gpurun_out/r02_cfg/bench_d13_arith.json 2>/dev/null
-python bench.py --degree-bits 19 --mix ecdsa --no-cpu-baseline --steps 6 --warmup 2 --pipelined 0 > gpurun_out/r02_cfg/bench_d19_ecdsa.json 2>/dev/null
+python bench.py --degree-bits 19 --mix ecdsa --no-cpu-baseline --steps 8 --warmup 4 --pipelined 0 > gpurun_out/r02_cfg/bench_d19_ecdsa.json 2>/dev/null
 python bench.py --degree-bits 21 --mix sha --no-cpu-baseline --steps 4 --warmup 1 --pipelined 0 --profile-steps 2 > gpurun_out/r02_cfg/bench_d21_sha.json 2>/dev/null
 for f in gpurun_out/r02_cfg/*.json; do python - "$f" <<'PY'
 import sys,json
 try:
     d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][0])
-    print(sys.argv[1].split('/')[-1], round(d['ms_per_step'],3), 'ms/proof', round(d['value'],2), 'proofs/s', 'host', d['host_witness'] and round(d['host_witness']['ms_per_proof'],2), 'pipe', d['pipelined'] and round(d['pipelined']['proofs_per_sec'],1))
+    print(sys.argv[1].split('/')[-1], round(d['value'],2), 'proofs/s with', d['in_flight_per_gpu'], 'in flight;', round(d['latency_ms_single_proof'],3), 'ms lone proof; host witness', d['host_witness'] and round(d['host_witness']['ms_per_proof'],2), 'ms')
 except Exception as e: print(sys.argv[1], 'ERR', e)
 PY
 done

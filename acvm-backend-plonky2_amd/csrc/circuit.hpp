@@ -212,6 +212,10 @@ struct CircuitState {
   bool wires_ntt_done = false;        // set by p2gpu_prove: coefficients + LDE of the wires already enqueued
   bool wires_hash_done = false;       // ... and the leaf digests too (incremental sponge, hash_state)
   DBuf<uint64_t> hash_state;          // [cosets][25][n] sponge states between column chunks (allocated on first use)
+  DBuf<uint32_t> wire_nz;             // [W] per proof: 0 = the wire column is identically zero (its transforms are elided)
+  DBuf<uint32_t> wire_nzlist;         // [1 + W]: count, then the indices of the non-zero wire columns
+  DBuf<uint32_t> wire_clean;          // [W] across proofs: 1 = wires.coeffs / wires.lde of the column hold zeros already
+  int zero_columns = 1;               // knob "zero_columns": elide the transforms of all-zero wire columns
   // tables
   DBuf<gl_t> tw_fwd, tw_inv, scale, inv_scale, d_kis, d_sigmas, fri_scale, qconst;
   DBuf<GateDesc> d_gates;

@@ -38,10 +38,17 @@ void ext_powers_bitrev(hipStream_t st, ext_t base, uint32_t d, gl_t *out) {
 // grid (parts, cols)
 __global__ __launch_bounds__(256) void eval_columns_kernel(const gl_t *__restrict__ coeffs, uint32_t d,
                                                            const gl_t *__restrict__ pw, uint32_t parts,
-                                                           gl_t *__restrict__ partial) {
+                                                           gl_t *__restrict__ partial, const uint32_t *__restrict__ colnz) {
   __shared__ gl_t s0[256], s1[256];
   const uint32_t n = 1u << d;
   const uint32_t part = blockIdx.x, col = blockIdx.y;
+  if (colnz != nullptr && colnz[col] == 0) {  // zero polynomial (an unused wire): opens to zero
+    if (threadIdx.x == 0) {
+      partial[((size_t)col * parts + part) * 2] = 0;
+      partial[((size_t)col * parts + part) * 2 + 1] = 0;
+    }
+    return;
+  }
   const uint32_t per = n / parts;
   const gl_t *c = coeffs + (size_t)col * n + (size_t)part * per;
   const gl_t *p0 = pw + (size_t)part * per, *p1 = pw + n + (size_t)part * per;
@@ -69,10 +76,10 @@ __global__ __launch_bounds__(256) void eval_columns_kernel(const gl_t *__restric
   }
 }
 void eval_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *pw, uint32_t parts,
-                  gl_t *partial) {
+                  gl_t *partial, const uint32_t *colnz) {
   if (!cols) return;
   ProfScope ps("eval_columns_kernel", 8.0 * cols * (double)((size_t)1 << d));
-  hipLaunchKernelGGL(eval_columns_kernel, dim3(parts, cols), dim3(256), 0, st, coeffs, d, pw, parts, partial);
+  hipLaunchKernelGGL(eval_columns_kernel, dim3(parts, cols), dim3(256), 0, st, coeffs, d, pw, parts, partial, colnz);
 }
 
 // block = 64 positions x 4 column groups: group g sums the columns j = g mod 4 (8 loads in flight
@@ -80,7 +87,8 @@ void eval_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d,
 // SIMD at n = 2^17, each walking 354 columns with a single load in flight.)
 __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restrict__ coeffs, uint32_t cols, uint32_t d,
                                                              const gl_t *__restrict__ apow, uint32_t j0,
-                                                             gl_t *__restrict__ acc, int accumulate) {
+                                                             gl_t *__restrict__ acc, int accumulate,
+                                                             const uint32_t *__restrict__ nzlist) {
   __shared__ gl_t red[2][4][64];
   const uint32_t n = 1u << d;
   const uint32_t p = blockIdx.x * 64 + threadIdx.x;
@@ -91,22 +99,31 @@ __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restr
     Acc160 l0, l1;  // unreduced sums of products (gl.hpp)
     l0.clear();
     l1.clear();
+    // nzlist (optional): nzlist[0] = number of non-zero columns, nzlist[1..] their indices, ascending -- the zero
+    // polynomials (unused wires) add no term and are not read; indices come through scalar loads
+    const uint32_t cnt = nzlist ? nzlist[0] : cols;
+    auto colof = [&](uint32_t i) { return nzlist ? nzlist[1 + i] : i; };
     uint32_t j = g;
 #pragma unroll 1
-    for (; j + 28 < cols; j += 32) {
+    for (; j + 28 < cnt; j += 32) {
       gl_t v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = coeffs[(size_t)(j + 4 * u) * n + p];
+      uint32_t cj[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        l0.mac(v[u], apow[2 * (j0 + j + 4 * u)]);
-        l1.mac(v[u], apow[2 * (j0 + j + 4 * u) + 1]);
+        cj[u] = colof(j + 4 * u);
+        v[u] = coeffs[(size_t)cj[u] * n + p];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        l0.mac(v[u], apow[2 * (j0 + cj[u])]);
+        l1.mac(v[u], apow[2 * (j0 + cj[u]) + 1]);
       }
     }
-    for (; j < cols; j += 4) {
-      const gl_t v = coeffs[(size_t)j * n + p];
-      l0.mac(v, apow[2 * (j0 + j)]);
-      l1.mac(v, apow[2 * (j0 + j) + 1]);
+    for (; j < cnt; j += 4) {
+      const uint32_t cj = colof(j);
+      const gl_t v = coeffs[(size_t)cj * n + p];
+      l0.mac(v, apow[2 * (j0 + cj)]);
+      l1.mac(v, apow[2 * (j0 + cj) + 1]);
     }
     a0 = l0.value();
     a1 = l1.value();
@@ -126,12 +143,23 @@ __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restr
   acc[p] = a0;
   acc[(size_t)n + p] = a1;
 }
+// list[0] = count, list[1..] = indices of the flagged columns, ascending (one thread: W is a few hundred)
+__global__ void compact_nonzero_kernel(const uint32_t *flags, uint32_t cols, uint32_t *list) {
+  if (blockIdx.x || threadIdx.x) return;
+  uint32_t k = 0;
+  for (uint32_t j = 0; j < cols; j++)
+    if (flags[j]) list[1 + k++] = j;
+  list[0] = k;
+}
+void compact_nonzero(hipStream_t st, const uint32_t *flags, uint32_t cols, uint32_t *list) {
+  hipLaunchKernelGGL(compact_nonzero_kernel, dim3(1), dim3(64), 0, st, flags, cols, list);
+}
 void reduce_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *apow, uint32_t j0,
-                    gl_t *acc, bool accumulate) {
+                    gl_t *acc, bool accumulate, const uint32_t *nzlist) {
   uint32_t n = 1u << d;
   ProfScope ps("reduce_columns_kernel", 8.0 * (cols + 4.0) * (double)n);
   hipLaunchKernelGGL(reduce_columns_kernel, dim3((n + 63) / 64), dim3(64, 4), 0, st, coeffs, cols, d, apow, j0, acc,
-                     accumulate ? 1 : 0);
+                     accumulate ? 1 : 0, nzlist);
 }
 
 __global__ __launch_bounds__(256) void fri_quotient_values_kernel(const gl_t *F0, const gl_t *F1, uint32_t d,

@@ -48,8 +48,15 @@ void ntt_plan_destroy(NttPlan *p);
 // src [cols][n] (or [cosets][cols][n] when src_per_coset), dst [cosets][cols][n]; stride_cols != 0: the
 // launch covers `cols` columns of a batch that has stride_cols columns per coset (chunked pipelines).
 // scale (DIT only): [cosets][n] multiplied into the input; post: multiplied into the output.
+// colnz (optional, [cols]): 0 marks an identically zero column -- its blocks store zeros / return (zero-column elision).
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
-               const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm = CosetMap(), uint32_t stride_cols = 0);
+               const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm = CosetMap(), uint32_t stride_cols = 0,
+               const uint32_t *colnz = nullptr, const uint32_t *colclean = nullptr);
+// colclean[c] = 1: dst already holds the zeros of zero column c.  `after` = false, enqueued before the transforms:
+// non-zero columns lose the mark; `after` = true, enqueued behind them: zero columns gain it.
+void column_clean_update(hipStream_t st, const uint32_t *nz, uint32_t cols, uint32_t *clean, bool after);
+// flags[c] = 1 iff column c of vals [cols][n] holds a non-zero element
+void column_flags(hipStream_t st, const gl_t *vals, uint32_t cols, uint32_t d, uint32_t *flags);
 void fill_powers(hipStream_t st, gl_t *out, gl_t root, uint32_t count);
 void fill_coset_scale(hipStream_t st, gl_t *out, gl_t shift, gl_t wN, uint32_t d, uint32_t cosets, gl_t mult);
 void bitrev_cols(hipStream_t st, const gl_t *in, gl_t *out, uint32_t d, uint32_t cols);
@@ -128,11 +135,14 @@ void fill_witness(hipStream_t st, gl_t *wires, const uint8_t *row_gate, const Ga
 // pw[p] = base^(bitrev_d(p)) over the extension: out [2][n]
 void ext_powers_bitrev(hipStream_t st, ext_t base, uint32_t d, gl_t *out);
 // partial dot products: for each column c of coeffs [cols][n]: sum_p coeffs[c][p] * pw[p]; parts per column
+// colnz (optional, [cols]): 0 = the column is the zero polynomial (elided: it opens to zero / adds no term)
 void eval_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *pw, uint32_t parts,
-                  gl_t *partial /* [cols][parts][2] */);
+                  gl_t *partial /* [cols][parts][2] */, const uint32_t *colnz = nullptr);
 // acc[2][n] (+)= sum_j apow[j0 + j] * coeffs[j][p]
 void reduce_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *apow /*[.][2]*/,
-                    uint32_t j0, gl_t *acc, bool accumulate);
+                    uint32_t j0, gl_t *acc, bool accumulate, const uint32_t *nzlist = nullptr);
+// nzlist form of the zero-column flags: list[0] = count, list[1..] = indices of the non-zero columns
+void compact_nonzero(hipStream_t st, const uint32_t *flags, uint32_t cols, uint32_t *list);
 // final[k] = aK * (F0[k] - f0z) / (x_k - zeta) + (F1[k] - f1z) / (x_k - gzeta), x_k = w_n^k
 void fri_quotient_values(hipStream_t st, const gl_t *F0, const gl_t *F1, uint32_t d, const gl_t *tw, uint32_t tw_shift,
                          ext_t zeta, ext_t gzeta, ext_t f0z, ext_t f1z, ext_t aK, gl_t *out /*[2][n]*/);

@@ -24,6 +24,7 @@
 // modmul is ~29 VALU); the HBM traffic equals the algorithmic bytes.  No MFMA.
 #include "internal.hpp"
 #include "glphi.hpp"
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -166,6 +167,11 @@ struct PassArgs {
   uint32_t nrounds;
   uint32_t r[MAX_ROUNDS];       // layers per round, ascending tile bit
   uint32_t tw_off[MAX_ROUNDS];  // offset of the round's table in ptw
+  const uint32_t *colnz;        // optional [cols]: 0 = the column is identically zero, so is its transform
+  uint32_t zero_fill;           // this pass writes dst from another buffer: zero columns are written as zeros;
+                                // the in-place passes after it leave them alone
+  const uint32_t *colclean;     // optional [cols]: 1 = dst already holds zeros for this column (an earlier proof on
+                                // the same handle stored them and nothing has written there since): not even stored
 };
 
 __device__ __forceinline__ uint32_t gidx(uint32_t e, uint32_t hi_base, uint32_t lo0, uint32_t s, uint32_t tb) {
@@ -363,6 +369,22 @@ __global__ __launch_bounds__(TBC ? NTT_THREADS : 256, NTT_MIN_WAVES) void ntt_pa
   const bool glin = (1u << A.tb) <= (uint32_t)NT12;
   const uint32_t g0 = gidx(threadIdx.x, hi_base, lo0, A.s, A.tb), gstep = (NT12 >> (glin ? A.tb : 0)) << A.s;
   const uint32_t l0 = pidx(threadIdx.x);
+  // Zero-column elision: a linear transform maps the zero column to the zero column, whatever the coset.
+  // Circuits of the reference that use no ECC gate leave wires 80..233 of the 234-wire configuration unused
+  // (zero in every row): their blocks store zeros (first pass) or return (in-place passes) -- block-uniform
+  // scalar branch, bit-identical output.
+  if (A.colnz != nullptr && A.colnz[col] == 0) {
+    if (A.zero_fill && !(A.colclean != nullptr && A.colclean[col] != 0)) {
+      if constexpr (TBC != 0) {
+#pragma unroll
+        for (int i = 0; i < NTT_PER; i++)
+          dst[glin ? g0 + (uint32_t)i * gstep : gidx(threadIdx.x + i * NT12, hi_base, lo0, A.s, A.tb)] = 0;
+      } else {
+        for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) dst[gidx(e, hi_base, lo0, A.s, A.tb)] = 0;
+      }
+    }
+    return;
+  }
   if constexpr (TBC != 0) {
     constexpr int PER = NTT_PER, NT = (1 << TBC) / PER;
     static_assert(NT == NT12, "full tile: NTT_THREADS lanes");
@@ -539,7 +561,8 @@ void ntt_plan_destroy(NttPlan *p) {
 }
 
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
-               const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_cols) {
+               const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_cols, const uint32_t *colnz,
+               const uint32_t *colclean) {
   if (cols == 0) return;
   const uint32_t d = plan->d;
   const size_t np = plan->passes.size();
@@ -558,6 +581,9 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     A.coset_first = cm.first;
     A.coset_stride = cm.stride;
     A.nrounds = ps.nrounds;
+    A.colnz = colnz;
+    A.colclean = colclean;
+    A.zero_fill = (i == 0) ? 1 : 0;
     for (int k = 0; k < MAX_ROUNDS; k++) { A.r[k] = ps.r[k]; A.tw_off[k] = ps.tw_off[k]; }
     const uint32_t TB = A.a + A.tb;
     const uint32_t tiles = 1u << (d - TB);
@@ -591,6 +617,43 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     }
 #undef P2_LAUNCH
   }
+}
+
+// ---- zero-column flags --------------------------------------------------------------
+// flags[c] = 1 iff column c of vals [cols][n] has a non-zero element (flags zeroed by the launcher)
+__global__ __launch_bounds__(256) void column_nonzero_kernel(const gl_t *__restrict__ vals, uint32_t d, uint32_t *flags) {
+  const size_t n = (size_t)1 << d;
+  const gl_t *p = vals + (size_t)blockIdx.y * n;
+  uint64_t acc = 0;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 8
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) acc |= p[i];
+  if (__any(acc != 0) && (threadIdx.x & 63) == 0) flags[blockIdx.y] = 1;
+}
+// "clean" bookkeeping of the buffers a column's transforms are written to (coefficients + LDE), so that the zeros of
+// an unused wire are stored once per handle instead of once per proof.  Both steps are stream-ordered around the
+// transforms: BEFORE them a non-zero column loses its clean mark (its buffers are about to be overwritten), AFTER them
+// a zero column gains it (its buffers now hold zeros).  Anything that aborts in between leaves marks only cleared.
+__global__ void column_clean_kernel(const uint32_t *nz, uint32_t cols, uint32_t *clean, int after) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  if (after) {
+    if (nz[c] == 0) clean[c] = 1;
+  } else {
+    if (nz[c] != 0) clean[c] = 0;
+  }
+}
+void column_clean_update(hipStream_t st, const uint32_t *nz, uint32_t cols, uint32_t *clean, bool after) {
+  if (!cols) return;
+  hipLaunchKernelGGL(column_clean_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, nz, cols, clean, after ? 1 : 0);
+}
+void column_flags(hipStream_t st, const gl_t *vals, uint32_t cols, uint32_t d, uint32_t *flags) {
+  if (!cols) return;
+  (void)hipMemsetAsync(flags, 0, sizeof(uint32_t) * cols, st);
+  const size_t n = (size_t)1 << d;
+  const uint32_t bx = (uint32_t)std::max<size_t>(1, n / (256 * 8));
+  ProfScope ps("column_nonzero_kernel", 8.0 * cols * (double)n);
+  hipLaunchKernelGGL(column_nonzero_kernel, dim3(bx, cols), dim3(256), 0, st, vals, d, flags);
 }
 
 // ---- tables -------------------------------------------------------------------

@@ -294,9 +294,16 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
 }
 
 // coefficients (bit-reversed storage) -> LDE on the 2^rate_bits cosets -> leaf digests -> tree
+// the zero-column flags of a batch: only the wires have them (valid for the proof in progress)
+const uint32_t *batch_colnz(const p2gpu_circuit *c, const Batch &b) {
+  return (&b == &c->wires && c->zero_columns && c->wire_nz.p) ? c->wire_nz.p : nullptr;
+}
 int batch_commit_from_coeffs(p2gpu_circuit *c, Batch &b) {
   {
-    ntt_batch(c->stream, c->plan_fwd, b.coeffs.p, b.lde.p, b.cols, b.ncl, c->scale.p, 1, false, b.cm);
+    const uint32_t *nz = batch_colnz(c, b);
+    ntt_batch(c->stream, c->plan_fwd, b.coeffs.p, b.lde.p, b.cols, b.ncl, c->scale.p, 1, false, b.cm, 0, nz,
+              nz ? c->wire_clean.p : nullptr);
+    if (nz) column_clean_update(c->stream, nz, b.cols, c->wire_clean.p, true);
   }
   {
     hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p, hprc(c));
@@ -313,8 +320,16 @@ int batch_commit_from_lde(p2gpu_circuit *c, Batch &b) {
 int batch_commit_from_values(p2gpu_circuit *c, Batch &b, const gl_t *vals_dev) {
   if (&b == &c->wires && c->wires_ntt_done) return c->wires_hash_done ? tree_build(c, b, c->n) : batch_commit_from_lde(c, b);
   {
+    // unused wires are zero in every row (wires 80..233 of the 234-wire configuration in circuits without ECC
+    // gates): one pass over the witness finds them, and their inverse transform and LDE become stores of zeros
+    const uint32_t *nz = batch_colnz(c, b);
+    if (nz) {
+      column_flags(c->stream, vals_dev, b.cols, c->d, c->wire_nz.p);
+      column_clean_update(c->stream, nz, b.cols, c->wire_clean.p, false);
+    }
     gl_t ninv = gl_inv((gl_t)c->n);
-    ntt_batch(c->stream, c->plan_inv, vals_dev, b.coeffs.p, b.cols, 1, nullptr, ninv, false);
+    ntt_batch(c->stream, c->plan_inv, vals_dev, b.coeffs.p, b.cols, 1, nullptr, ninv, false, CosetMap(), 0, nz,
+              nz ? c->wire_clean.p : nullptr);
   }
   TRACE(c, "  inverse ntt");
   return batch_commit_from_coeffs(c, b);
@@ -516,9 +531,11 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     while (parts < 16 && (n / (parts * 2)) >= 1024) parts *= 2;
     ext_powers_bitrev(st, zeta, d, c->pw.p);
     ext_powers_bitrev(st, gzeta, d, c->pw.p + 2 * n);
+    if (batch_colnz(c, c->wires)) compact_nonzero(st, c->wire_nz.p, c->W, c->wire_nzlist.p);
     size_t base = 0;
     for (int o = 0; o < 4; o++) {
-      eval_columns(st, oracles[o]->coeffs.p, oracles[o]->cols, d, c->pw.p, parts, c->partial.p + base * parts * 2);
+      eval_columns(st, oracles[o]->coeffs.p, oracles[o]->cols, d, c->pw.p, parts, c->partial.p + base * parts * 2,
+                   batch_colnz(c, *oracles[o]));
       base += oracles[o]->cols;
     }
     {
@@ -564,7 +581,8 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     gl_t *F0 = c->f01.p, *F1 = c->f01.p + 2 * n;
     uint32_t j0 = 0;
     for (int o = 0; o < 4; o++) {
-      reduce_columns(st, oracles[o]->coeffs.p, oracles[o]->cols, d, c->ext_apow.p, j0, F0, o != 0);
+      reduce_columns(st, oracles[o]->coeffs.p, oracles[o]->cols, d, c->ext_apow.p, j0, F0, o != 0,
+                     batch_colnz(c, *oracles[o]) ? c->wire_nzlist.p : nullptr);
       j0 += oracles[o]->cols;
     }
     {
@@ -848,6 +866,9 @@ void circuit_release(p2gpu_circuit *c) {
   for (auto &b : c->fri_vals) b.release();
   for (auto &b : c->fri_trees) b.release();
   c->hash_state.release();
+  c->wire_nz.release();
+  c->wire_nzlist.release();
+  c->wire_clean.release();
   c->pin.release();
   c->pow_result.release(); c->gather_ptrs.release(); c->gather_out.release(); c->xchg_recv.release();
   ntt_plan_destroy(c->plan_inv);
@@ -1095,6 +1116,10 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     return P2GPU_E_DEVICE;
   }
   CK(c->wires_vals.alloc((size_t)c->W * n), "alloc wires");
+  CK(c->wire_nz.alloc(c->W), "alloc wire flags");
+  CK(c->wire_nzlist.alloc(c->W + 1), "alloc wire flags");
+  CK(c->wire_clean.alloc(c->W), "alloc wire flags");
+  CK(hipMemsetAsync(c->wire_clean.p, 0, sizeof(uint32_t) * c->W, c->stream), "clear wire flags");
   CK(c->zp_vals.alloc((size_t)nzp * n), "alloc zp");
   CK(c->cp.alloc((size_t)K * c->nchunks * n), "alloc cp");
   CK(c->rowprod.alloc((size_t)K * n), "alloc rowprod");
@@ -1208,6 +1233,11 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
   if (k == "pow_hint") c->pow_hint = value;
   else if (k == "self_check") c->self_check = (int)value;
   else if (k == "shard_exercise") c->shard_exercise = (int)value;
+  else if (k == "zero_columns") {
+    c->zero_columns = (int)value;
+    // proofs made with the knob off overwrite every column without touching the marks: forget them
+    if (c->wire_clean.p) HIP_TRY(hipMemsetAsync(c->wire_clean.p, 0, sizeof(uint32_t) * c->W, c->stream));
+  }
   else if (k == "profile") {
     flush_kstats(c);
     c->profile = (int)value;
@@ -1249,6 +1279,8 @@ static int shard_layout(p2gpu_circuit *c, int rank, int world) {
     t0.cm = cm;
     tree_layout(t0, ncl, c->n >> c->arity[0], cap_per);
   }
+  // a different number of local cosets changes which part of wires.lde a column's transforms cover
+  if (c->wire_clean.p) HIP_TRY(hipMemsetAsync(c->wire_clean.p, 0, sizeof(uint32_t) * c->W, c->stream));
   c->xchg_recv.release();
   // receive side of the largest exchange: quotient interpolants (K * C * n words in total) or the query gather
   HIP_TRY(c->xchg_recv.alloc(std::max((size_t)world * c->gather_cap, (size_t)c->K * c->C * c->n) + 64));
@@ -1403,9 +1435,16 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
     HIP_TRY(hipMemcpyAsync(vals, wires + (size_t)col0 * n, 8 * (size_t)nc * n, hipMemcpyHostToDevice, c->copy_stream));
     HIP_TRY(hipEventRecord(c->copy_events[ci], c->copy_stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->copy_events[ci], 0));
-    ntt_batch(c->stream, c->plan_inv, vals, b.coeffs.p + (size_t)col0 * n, nc, 1, nullptr, ninv, false);
+    const uint32_t *nz = batch_colnz(c, b) ? c->wire_nz.p + col0 : nullptr;
+    uint32_t *cl = nz ? c->wire_clean.p + col0 : nullptr;
+    if (nz) {
+      column_flags(c->stream, vals, nc, c->d, c->wire_nz.p + col0);
+      column_clean_update(c->stream, nz, nc, cl, false);
+    }
+    ntt_batch(c->stream, c->plan_inv, vals, b.coeffs.p + (size_t)col0 * n, nc, 1, nullptr, ninv, false, CosetMap(), 0, nz, cl);
     ntt_batch(c->stream, c->plan_fwd, b.coeffs.p + (size_t)col0 * n, b.lde.p + (size_t)col0 * n, nc, b.ncl, c->scale.p, 1,
-              false, b.cm, W);
+              false, b.cm, W, nz, cl);
+    if (nz) column_clean_update(c->stream, nz, nc, cl, true);
     if (incremental) {
       const bool last = col0 + chunk >= W;
       const uint32_t blk0 = col0 / 17;

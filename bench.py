@@ -165,8 +165,8 @@ def cpu_baseline(pkg, d, mix, n_pi, single_thread_bits):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--degree-bits", type=int, default=17)
     ap.add_argument("--mix", default="sha")
     ap.add_argument("--workload", choices=["synth", "sha256"], default="synth",

@@ -192,7 +192,9 @@ int p2gpu_verify_compressed(const p2gpu_circuit *c, const uint8_t *cproof, size_
  * witness does not satisfy the circuit; 0 = emit the proof anyway like upstream), "shard_exercise" (0/1: with world = 1, still run the exchange steps of a sharded proof through the
  * configured transport -- how the RCCL path is tested on a one-GPU machine), "profile" (0 / 1 / 2: time kernel
  * launches with HIP events on the launch stream -- 1 = the launches that move >= 32 MB, 2 = every launch;
- * resets the statistics) */
+ * resets the statistics), "zero_columns" (0/1, default 1: one pass over the witness finds the wire columns that
+ * are zero in every row -- the wires no gate of the circuit uses -- and stores zeros instead of running their
+ * inverse transform and LDE; the proof bytes do not depend on it) */
 int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value);
 /* statistics accumulated while "profile" = 1, one entry per kernel symbol:
  * names[64*i] (NUL-terminated), total milliseconds, total algorithmic bytes,

@@ -136,6 +136,38 @@ def test_proof_bytes_match_oracle(pkg, orc, gpu, d, mix, seed):
     cd.close()
 
 
+@pytest.mark.parametrize("d,mix", [(5, "arith"), (10, "sha"), (13, "sha"), (13, "ecdsa")])
+def test_zero_column_elision_does_not_change_the_proof(pkg, orc, gpu, d, mix):
+    """Wire columns that are zero in every row (the unused wires: 154 of 234 in the sha / arith mixes, as in the
+    reference's circuits without ECC gates) are not transformed -- zeros are stored instead.  Same bytes with the
+    knob off, same bytes as the oracle, on the resident, the chunked host-witness and the routed entry points."""
+    import torch
+
+    blob, wires = pkg.make_circuit(d, mix, 77)
+    nz = int((wires.reshape(234, -1) != 0).any(axis=1).sum())
+    assert nz == 80 if mix != "ecdsa" else nz > 200
+    cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
+    expect, _ = oc.prove(wires)
+    wd = torch.from_numpy(wires.view(np.int64)).cuda()
+    for knob in (1, 0, 1):
+        cd.set("zero_columns", knob)
+        assert cd.prove(wd).to_bytes() == expect          # p2gpu_prove_dev
+        assert cd.prove(wires).to_bytes() == expect       # p2gpu_prove: column chunks, flags per chunk
+        assert cd.prove_routed(wires[:80]).to_bytes() == expect
+    # a witness whose zero / non-zero pattern changes from proof to proof on the same handle: stale zeros or stale
+    # values of the previous proof must not survive in the coefficient / LDE buffers
+    cd.set("self_check", 0)
+    oc2 = oc
+    for cols in ([5, 17, 79], [0, 40], []):
+        w2 = wires.copy()
+        for c_ in cols:
+            w2[c_, :] = 0
+        want, _ = oc2.prove(w2)   # an unsatisfied witness still yields (unverifiable) bytes, on both sides
+        assert cd.prove(torch.from_numpy(w2.view(np.int64)).cuda()).to_bytes() == want, cols
+        assert cd.prove(w2).to_bytes() == want, cols
+    cd.close()
+
+
 @pytest.mark.parametrize("d,mix,npi", [(6, "arith", 1), (8, "sha", 4), (9, "ecdsa", 9), (12, "ecdsa", 20)])
 def test_public_inputs_proof_bytes_match_oracle(pkg, orc, gpu, d, mix, npi):
     """PoseidonGate rows + Poseidon public_inputs_hash (InnerHasher) on the GPU path."""

@@ -212,7 +212,13 @@ struct CircuitState {
   bool wires_ntt_done = false;        // set by p2gpu_prove: coefficients + LDE of the wires already enqueued
   bool wires_hash_done = false;       // ... and the leaf digests too (incremental sponge, hash_state)
   DBuf<uint64_t> hash_state;          // [cosets][25][n] sponge states between column chunks (allocated on first use)
-  DBuf<uint32_t> wire_nz;             // [W] per proof: 0 = the wire column is identically zero (its transforms are elided)
+  DBuf<uint32_t> wire_nz;             // [W] per proof, class of the wire column: 0 zero in every row, 1 zero except in
+                                      // sparse_row, 2 dense (ColHints, internal.hpp); 0 and 1 are not transformed
+  DBuf<gl_t> wire_scalar;             // [W] per proof: value of a class 1 column in sparse_row
+  uint32_t sparse_row = UINT32_MAX;   // the PublicInputGate row: build() randomises its unused wires (UINT32_MAX: none)
+  DBuf<gl_t> sparse_coeffs, sparse_lde;  // inverse transform [n] and LDE [C][n] of the unit column of sparse_row
+  DBuf<gl_t> sparse_partial;          // per proof: [16][2] partial sums of the unit column's opening at zeta, then [2]:
+                                      // the class 1 columns' joint coefficient in the FRI batch reduction
   DBuf<uint32_t> wire_nzlist;         // [1 + W]: count, then the indices of the non-zero wire columns
   DBuf<uint32_t> wire_clean;          // [W] across proofs: 1 = wires.coeffs / wires.lde of the column hold zeros already
   int zero_columns = 1;               // knob "zero_columns": elide the transforms of all-zero wire columns

@@ -38,14 +38,24 @@ void ext_powers_bitrev(hipStream_t st, ext_t base, uint32_t d, gl_t *out) {
 // grid (parts, cols)
 __global__ __launch_bounds__(256) void eval_columns_kernel(const gl_t *__restrict__ coeffs, uint32_t d,
                                                            const gl_t *__restrict__ pw, uint32_t parts,
-                                                           gl_t *__restrict__ partial, const uint32_t *__restrict__ colnz) {
+                                                           gl_t *__restrict__ partial, const uint32_t *__restrict__ colnz,
+                                                           const gl_t *__restrict__ colval,
+                                                           const gl_t *__restrict__ basis_partial) {
   __shared__ gl_t s0[256], s1[256];
   const uint32_t n = 1u << d;
   const uint32_t part = blockIdx.x, col = blockIdx.y;
-  if (colnz != nullptr && colnz[col] == 0) {  // zero polynomial (an unused wire): opens to zero
+  if (colnz != nullptr && colnz[col] != 2) {
+    // class 0: the zero polynomial opens to zero; class 1: v times the unit column's polynomial, whose partial
+    // sums an earlier launch left in basis_partial [parts][2]
     if (threadIdx.x == 0) {
-      partial[((size_t)col * parts + part) * 2] = 0;
-      partial[((size_t)col * parts + part) * 2 + 1] = 0;
+      gl_t r0 = 0, r1 = 0;
+      if (colnz[col] == 1) {
+        const gl_t v = colval[col];
+        r0 = gl_mul(v, basis_partial[2 * part]);
+        r1 = gl_mul(v, basis_partial[2 * part + 1]);
+      }
+      partial[((size_t)col * parts + part) * 2] = r0;
+      partial[((size_t)col * parts + part) * 2 + 1] = r1;
     }
     return;
   }
@@ -76,10 +86,11 @@ __global__ __launch_bounds__(256) void eval_columns_kernel(const gl_t *__restric
   }
 }
 void eval_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *pw, uint32_t parts,
-                  gl_t *partial, const uint32_t *colnz) {
+                  gl_t *partial, const ColHints *hints, const gl_t *basis_partial) {
   if (!cols) return;
   ProfScope ps("eval_columns_kernel", 8.0 * cols * (double)((size_t)1 << d));
-  hipLaunchKernelGGL(eval_columns_kernel, dim3(parts, cols), dim3(256), 0, st, coeffs, d, pw, parts, partial, colnz);
+  hipLaunchKernelGGL(eval_columns_kernel, dim3(parts, cols), dim3(256), 0, st, coeffs, d, pw, parts, partial,
+                     hints ? hints->cls : nullptr, hints ? hints->val : nullptr, basis_partial);
 }
 
 // block = 64 positions x 4 column groups: group g sums the columns j = g mod 4 (8 loads in flight
@@ -88,7 +99,8 @@ void eval_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d,
 __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restrict__ coeffs, uint32_t cols, uint32_t d,
                                                              const gl_t *__restrict__ apow, uint32_t j0,
                                                              gl_t *__restrict__ acc, int accumulate,
-                                                             const uint32_t *__restrict__ nzlist) {
+                                                             const uint32_t *__restrict__ nzlist,
+                                                             const gl_t *__restrict__ basis, const gl_t *__restrict__ fold) {
   __shared__ gl_t red[2][4][64];
   const uint32_t n = 1u << d;
   const uint32_t p = blockIdx.x * 64 + threadIdx.x;
@@ -99,8 +111,9 @@ __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restr
     Acc160 l0, l1;  // unreduced sums of products (gl.hpp)
     l0.clear();
     l1.clear();
-    // nzlist (optional): nzlist[0] = number of non-zero columns, nzlist[1..] their indices, ascending -- the zero
-    // polynomials (unused wires) add no term and are not read; indices come through scalar loads
+    // nzlist (optional): nzlist[0] = number of dense columns, nzlist[1..] their indices, ascending -- the zero
+    // polynomials add no term, and the class 1 columns (v_j times the unit column's polynomial `basis`) are one
+    // term together: sum_j apow_j v_j basis[p], the sum precomputed in fold[2]; indices come through scalar loads
     const uint32_t cnt = nzlist ? nzlist[0] : cols;
     auto colof = [&](uint32_t i) { return nzlist ? nzlist[1 + i] : i; };
     uint32_t j = g;
@@ -125,6 +138,11 @@ __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restr
       l0.mac(v, apow[2 * (j0 + cj)]);
       l1.mac(v, apow[2 * (j0 + cj) + 1]);
     }
+    if (basis != nullptr && g == 3) {
+      const gl_t b = basis[p];
+      l0.mac(b, fold[0]);
+      l1.mac(b, fold[1]);
+    }
     a0 = l0.value();
     a1 = l1.value();
   }
@@ -143,23 +161,51 @@ __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restr
   acc[p] = a0;
   acc[(size_t)n + p] = a1;
 }
-// list[0] = count, list[1..] = indices of the flagged columns, ascending (one thread: W is a few hundred)
+// list[0] = count, list[1..] = indices of the DENSE columns (class 2), ascending (one thread: W is a few hundred)
 __global__ void compact_nonzero_kernel(const uint32_t *flags, uint32_t cols, uint32_t *list) {
   if (blockIdx.x || threadIdx.x) return;
   uint32_t k = 0;
   for (uint32_t j = 0; j < cols; j++)
-    if (flags[j]) list[1 + k++] = j;
+    if (flags[j] == 2) list[1 + k++] = j;
   list[0] = k;
 }
 void compact_nonzero(hipStream_t st, const uint32_t *flags, uint32_t cols, uint32_t *list) {
   hipLaunchKernelGGL(compact_nonzero_kernel, dim3(1), dim3(64), 0, st, flags, cols, list);
 }
+// fold[e] = sum over the class 1 columns j of apow[2 (j0 + j) + e] * val[j]   (e = 0, 1)
+__global__ __launch_bounds__(256) void class1_fold_kernel(const uint32_t *cls, const gl_t *val, uint32_t cols, const gl_t *apow,
+                                                          uint32_t j0, gl_t *fold) {
+  __shared__ gl_t s0[256], s1[256];
+  gl_t a0 = 0, a1 = 0;
+  for (uint32_t j = threadIdx.x; j < cols; j += blockDim.x)
+    if (cls[j] == 1) {
+      a0 = gl_add(a0, gl_mul(apow[2 * (j0 + j)], val[j]));
+      a1 = gl_add(a1, gl_mul(apow[2 * (j0 + j) + 1], val[j]));
+    }
+  s0[threadIdx.x] = a0;
+  s1[threadIdx.x] = a1;
+  __syncthreads();
+  for (uint32_t off = blockDim.x >> 1; off; off >>= 1) {
+    if (threadIdx.x < off) {
+      s0[threadIdx.x] = gl_add(s0[threadIdx.x], s0[threadIdx.x + off]);
+      s1[threadIdx.x] = gl_add(s1[threadIdx.x], s1[threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    fold[0] = s0[0];
+    fold[1] = s1[0];
+  }
+}
+void class1_fold(hipStream_t st, const ColHints &h, uint32_t cols, const gl_t *apow, uint32_t j0, gl_t *fold) {
+  hipLaunchKernelGGL(class1_fold_kernel, dim3(1), dim3(256), 0, st, h.cls, h.val, cols, apow, j0, fold);
+}
 void reduce_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *apow, uint32_t j0,
-                    gl_t *acc, bool accumulate, const uint32_t *nzlist) {
+                    gl_t *acc, bool accumulate, const uint32_t *nzlist, const gl_t *basis, const gl_t *fold) {
   uint32_t n = 1u << d;
   ProfScope ps("reduce_columns_kernel", 8.0 * (cols + 4.0) * (double)n);
   hipLaunchKernelGGL(reduce_columns_kernel, dim3((n + 63) / 64), dim3(64, 4), 0, st, coeffs, cols, d, apow, j0, acc,
-                     accumulate ? 1 : 0, nzlist);
+                     accumulate ? 1 : 0, nzlist, basis, fold);
 }
 
 __global__ __launch_bounds__(256) void fri_quotient_values_kernel(const gl_t *F0, const gl_t *F1, uint32_t d,

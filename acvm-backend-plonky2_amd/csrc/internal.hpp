@@ -48,15 +48,24 @@ void ntt_plan_destroy(NttPlan *p);
 // src [cols][n] (or [cosets][cols][n] when src_per_coset), dst [cosets][cols][n]; stride_cols != 0: the
 // launch covers `cols` columns of a batch that has stride_cols columns per coset (chunked pipelines).
 // scale (DIT only): [cosets][n] multiplied into the input; post: multiplied into the output.
-// colnz (optional, [cols]): 0 marks an identically zero column -- its blocks store zeros / return (zero-column elision).
+// Structured columns of a batch (the unused wires of a witness): a transform is linear, so the zero column maps to
+// zeros and v * (unit column of a fixed row) maps to v * (the transform of that unit column, kept by the handle).
+struct ColHints {
+  const uint32_t *cls = nullptr;    // [cols]: 0 zero, 1 = val[c] * unit column of the fixed row, 2 dense
+  const uint32_t *clean = nullptr;  // [cols], optional: 1 = dst already holds the zeros of class 0 column c
+  const gl_t *val = nullptr;        // [cols]: scalar of the class 1 columns
+  const gl_t *basis = nullptr;      // this transform of the unit column: [n], or [all cosets][n] (indexed by GLOBAL coset)
+  bool basis_per_coset = false;
+};
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
                const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm = CosetMap(), uint32_t stride_cols = 0,
-               const uint32_t *colnz = nullptr, const uint32_t *colclean = nullptr);
-// colclean[c] = 1: dst already holds the zeros of zero column c.  `after` = false, enqueued before the transforms:
+               const ColHints *hints = nullptr);
+// clean[c] = 1: dst already holds the zeros of zero column c.  `after` = false, enqueued before the transforms:
 // non-zero columns lose the mark; `after` = true, enqueued behind them: zero columns gain it.
-void column_clean_update(hipStream_t st, const uint32_t *nz, uint32_t cols, uint32_t *clean, bool after);
-// flags[c] = 1 iff column c of vals [cols][n] holds a non-zero element
-void column_flags(hipStream_t st, const gl_t *vals, uint32_t cols, uint32_t d, uint32_t *flags);
+void column_clean_update(hipStream_t st, const uint32_t *cls, uint32_t cols, uint32_t *clean, bool after);
+// class of every column of vals [cols][n] (see ColHints) with respect to `sparse_row` (UINT32_MAX: none)
+void column_flags(hipStream_t st, const gl_t *vals, uint32_t cols, uint32_t d, uint32_t sparse_row, uint32_t *flags,
+                  gl_t *scalar);
 void fill_powers(hipStream_t st, gl_t *out, gl_t root, uint32_t count);
 void fill_coset_scale(hipStream_t st, gl_t *out, gl_t shift, gl_t wN, uint32_t d, uint32_t cosets, gl_t mult);
 void bitrev_cols(hipStream_t st, const gl_t *in, gl_t *out, uint32_t d, uint32_t cols);
@@ -135,14 +144,18 @@ void fill_witness(hipStream_t st, gl_t *wires, const uint8_t *row_gate, const Ga
 // pw[p] = base^(bitrev_d(p)) over the extension: out [2][n]
 void ext_powers_bitrev(hipStream_t st, ext_t base, uint32_t d, gl_t *out);
 // partial dot products: for each column c of coeffs [cols][n]: sum_p coeffs[c][p] * pw[p]; parts per column
-// colnz (optional, [cols]): 0 = the column is the zero polynomial (elided: it opens to zero / adds no term)
+// hints (optional): class 0 columns open to zero; class 1 columns to val[c] times the unit column's partial sums
+// (basis_partial [parts][2], left by an earlier eval_columns launch over that one column)
 void eval_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *pw, uint32_t parts,
-                  gl_t *partial /* [cols][parts][2] */, const uint32_t *colnz = nullptr);
+                  gl_t *partial /* [cols][parts][2] */, const ColHints *hints = nullptr, const gl_t *basis_partial = nullptr);
 // acc[2][n] (+)= sum_j apow[j0 + j] * coeffs[j][p]
 void reduce_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *apow /*[.][2]*/,
-                    uint32_t j0, gl_t *acc, bool accumulate, const uint32_t *nzlist = nullptr);
-// nzlist form of the zero-column flags: list[0] = count, list[1..] = indices of the non-zero columns
+                    uint32_t j0, gl_t *acc, bool accumulate, const uint32_t *nzlist = nullptr, const gl_t *basis = nullptr,
+                    const gl_t *fold = nullptr);
+// nzlist: list[0] = count, list[1..] = indices of the dense (class 2) columns; fold[2]: the class 1 columns' joint
+// coefficient of the unit column's polynomial `basis` in the reduction
 void compact_nonzero(hipStream_t st, const uint32_t *flags, uint32_t cols, uint32_t *list);
+void class1_fold(hipStream_t st, const ColHints &h, uint32_t cols, const gl_t *apow, uint32_t j0, gl_t *fold);
 // final[k] = aK * (F0[k] - f0z) / (x_k - zeta) + (F1[k] - f1z) / (x_k - gzeta), x_k = w_n^k
 void fri_quotient_values(hipStream_t st, const gl_t *F0, const gl_t *F1, uint32_t d, const gl_t *tw, uint32_t tw_shift,
                          ext_t zeta, ext_t gzeta, ext_t f0z, ext_t f1z, ext_t aK, gl_t *out /*[2][n]*/);

@@ -167,11 +167,16 @@ struct PassArgs {
   uint32_t nrounds;
   uint32_t r[MAX_ROUNDS];       // layers per round, ascending tile bit
   uint32_t tw_off[MAX_ROUNDS];  // offset of the round's table in ptw
-  const uint32_t *colnz;        // optional [cols]: 0 = the column is identically zero, so is its transform
-  uint32_t zero_fill;           // this pass writes dst from another buffer: zero columns are written as zeros;
+  // structured columns (ColHints, internal.hpp): class 0 = identically zero, 1 = a multiple of the unit column of
+  // one fixed row (`colval` times the precomputed transform `basis` of that unit column), 2 = dense
+  const uint32_t *colnz;        // optional [cols]: the class of every column
+  uint32_t zero_fill;           // this pass writes dst from another buffer: class 0 / 1 columns are written here;
                                 // the in-place passes after it leave them alone
   const uint32_t *colclean;     // optional [cols]: 1 = dst already holds zeros for this column (an earlier proof on
                                 // the same handle stored them and nothing has written there since): not even stored
+  const gl_t *colval;           // [cols]: the scalar of a class 1 column
+  const gl_t *basis;            // [n] (or [all cosets][n] when basis_per_coset): this transform of the unit column
+  uint32_t basis_per_coset;
 };
 
 __device__ __forceinline__ uint32_t gidx(uint32_t e, uint32_t hi_base, uint32_t lo0, uint32_t s, uint32_t tb) {
@@ -373,7 +378,8 @@ __global__ __launch_bounds__(TBC ? NTT_THREADS : 256, NTT_MIN_WAVES) void ntt_pa
   // Circuits of the reference that use no ECC gate leave wires 80..233 of the 234-wire configuration unused
   // (zero in every row): their blocks store zeros (first pass) or return (in-place passes) -- block-uniform
   // scalar branch, bit-identical output.
-  if (A.colnz != nullptr && A.colnz[col] == 0) {
+  const uint32_t cls = A.colnz != nullptr ? A.colnz[col] : 2u;
+  if (cls == 0) {
     if (A.zero_fill && !(A.colclean != nullptr && A.colclean[col] != 0)) {
       if constexpr (TBC != 0) {
 #pragma unroll
@@ -381,6 +387,31 @@ __global__ __launch_bounds__(TBC ? NTT_THREADS : 256, NTT_MIN_WAVES) void ntt_pa
           dst[glin ? g0 + (uint32_t)i * gstep : gidx(threadIdx.x + i * NT12, hi_base, lo0, A.s, A.tb)] = 0;
       } else {
         for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) dst[gidx(e, hi_base, lo0, A.s, A.tb)] = 0;
+      }
+    }
+    return;
+  }
+  if (cls == 1) {
+    // v * (unit column of the fixed row): by linearity its transform is v times the unit column's transform, which
+    // the circuit handle holds -- one product per element instead of the whole network, the same canonical values
+    if (A.zero_fill) {
+      const gl_t v = A.colval[col];
+      const gl_t *bs = A.basis + (A.basis_per_coset ? (size_t)(A.coset_first + coset * A.coset_stride) * n : 0);
+      if constexpr (TBC != 0) {
+        gl_t bv[NTT_PER];
+        uint32_t gi[NTT_PER];
+#pragma unroll
+        for (int i = 0; i < NTT_PER; i++) {
+          gi[i] = glin ? g0 + (uint32_t)i * gstep : gidx(threadIdx.x + i * NT12, hi_base, lo0, A.s, A.tb);
+          bv[i] = bs[gi[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < NTT_PER; i++) dst[gi[i]] = gl_mul(v, bv[i]);
+      } else {
+        for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
+          const uint32_t g = gidx(e, hi_base, lo0, A.s, A.tb);
+          dst[g] = gl_mul(v, bs[g]);
+        }
       }
     }
     return;
@@ -561,8 +592,7 @@ void ntt_plan_destroy(NttPlan *p) {
 }
 
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
-               const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_cols, const uint32_t *colnz,
-               const uint32_t *colclean) {
+               const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_cols, const ColHints *hints) {
   if (cols == 0) return;
   const uint32_t d = plan->d;
   const size_t np = plan->passes.size();
@@ -581,8 +611,11 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     A.coset_first = cm.first;
     A.coset_stride = cm.stride;
     A.nrounds = ps.nrounds;
-    A.colnz = colnz;
-    A.colclean = colclean;
+    A.colnz = hints ? hints->cls : nullptr;
+    A.colclean = hints ? hints->clean : nullptr;
+    A.colval = hints ? hints->val : nullptr;
+    A.basis = hints ? hints->basis : nullptr;
+    A.basis_per_coset = hints && hints->basis_per_coset ? 1 : 0;
     A.zero_fill = (i == 0) ? 1 : 0;
     for (int k = 0; k < MAX_ROUNDS; k++) { A.r[k] = ps.r[k]; A.tw_off[k] = ps.tw_off[k]; }
     const uint32_t TB = A.a + A.tb;
@@ -620,15 +653,32 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
 }
 
 // ---- zero-column flags --------------------------------------------------------------
-// flags[c] = 1 iff column c of vals [cols][n] has a non-zero element (flags zeroed by the launcher)
-__global__ __launch_bounds__(256) void column_nonzero_kernel(const gl_t *__restrict__ vals, uint32_t d, uint32_t *flags) {
+// Class of every column of vals [cols][n] (flags zeroed by the launcher): 0 = zero in every row; 1 = zero in every
+// row but `sparse_row`, whose value goes to scalar[c]; 2 = anything else.  plonky2's build() hangs a random value
+// on every unused wire of the PublicInputGate row (circuit_builder.rs randomize_unused_pi_wires; visible in the
+// reference's own proofs, tests/golden/reference_proofs.py), so in a real witness the wires no gate uses are
+// class 1 with that row, not class 0.  sparse_row = UINT32_MAX: no such row.
+__global__ __launch_bounds__(256) void column_nonzero_kernel(const gl_t *__restrict__ vals, uint32_t d, uint32_t sparse_row,
+                                                             uint32_t *flags, gl_t *scalar) {
   const size_t n = (size_t)1 << d;
   const gl_t *p = vals + (size_t)blockIdx.y * n;
   uint64_t acc = 0;
   const size_t step = (size_t)gridDim.x * blockDim.x;
 #pragma unroll 8
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) acc |= p[i];
-  if (__any(acc != 0) && (threadIdx.x & 63) == 0) flags[blockIdx.y] = 1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const gl_t v = p[i];
+    acc |= (i == sparse_row) ? (gl_t)0 : v;  // a select, not a branch: the loads stay batched
+  }
+  // dense: a plain store (every wave of a dense column would otherwise hammer one address with atomics); it
+  // and the atomicMax below commute: 2 wins either way
+  if (__any(acc != 0) && (threadIdx.x & 63) == 0) flags[blockIdx.y] = 2u;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && sparse_row < n) {
+    const gl_t v = p[sparse_row];
+    if (v != 0) {
+      scalar[blockIdx.y] = v;
+      atomicMax(&flags[blockIdx.y], 1u);
+    }
+  }
 }
 // "clean" bookkeeping of the buffers a column's transforms are written to (coefficients + LDE), so that the zeros of
 // an unused wire are stored once per handle instead of once per proof.  Both steps are stream-ordered around the
@@ -647,13 +697,14 @@ void column_clean_update(hipStream_t st, const uint32_t *nz, uint32_t cols, uint
   if (!cols) return;
   hipLaunchKernelGGL(column_clean_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, nz, cols, clean, after ? 1 : 0);
 }
-void column_flags(hipStream_t st, const gl_t *vals, uint32_t cols, uint32_t d, uint32_t *flags) {
+void column_flags(hipStream_t st, const gl_t *vals, uint32_t cols, uint32_t d, uint32_t sparse_row, uint32_t *flags,
+                  gl_t *scalar) {
   if (!cols) return;
   (void)hipMemsetAsync(flags, 0, sizeof(uint32_t) * cols, st);
   const size_t n = (size_t)1 << d;
   const uint32_t bx = (uint32_t)std::max<size_t>(1, n / (256 * 8));
   ProfScope ps("column_nonzero_kernel", 8.0 * cols * (double)n);
-  hipLaunchKernelGGL(column_nonzero_kernel, dim3(bx, cols), dim3(256), 0, st, vals, d, flags);
+  hipLaunchKernelGGL(column_nonzero_kernel, dim3(bx, cols), dim3(256), 0, st, vals, d, sparse_row, flags, scalar);
 }
 
 // ---- tables -------------------------------------------------------------------

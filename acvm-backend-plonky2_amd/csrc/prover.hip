@@ -294,15 +294,25 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
 }
 
 // coefficients (bit-reversed storage) -> LDE on the 2^rate_bits cosets -> leaf digests -> tree
-// the zero-column flags of a batch: only the wires have them (valid for the proof in progress)
+// the column classes of a batch: only the wires have them (valid for the proof in progress)
 const uint32_t *batch_colnz(const p2gpu_circuit *c, const Batch &b) {
   return (&b == &c->wires && c->zero_columns && c->wire_nz.p) ? c->wire_nz.p : nullptr;
+}
+// hints for the transforms of the wire columns [col0, ...): lde = false: values -> coefficients, true: the LDE
+ColHints wire_hints(const p2gpu_circuit *c, uint32_t col0, bool lde) {
+  ColHints h;
+  h.cls = c->wire_nz.p + col0;
+  h.clean = c->wire_clean.p + col0;
+  h.val = c->wire_scalar.p + col0;
+  h.basis = lde ? c->sparse_lde.p : c->sparse_coeffs.p;
+  h.basis_per_coset = lde;
+  return h;
 }
 int batch_commit_from_coeffs(p2gpu_circuit *c, Batch &b) {
   {
     const uint32_t *nz = batch_colnz(c, b);
-    ntt_batch(c->stream, c->plan_fwd, b.coeffs.p, b.lde.p, b.cols, b.ncl, c->scale.p, 1, false, b.cm, 0, nz,
-              nz ? c->wire_clean.p : nullptr);
+    const ColHints h = nz ? wire_hints(c, 0, true) : ColHints();
+    ntt_batch(c->stream, c->plan_fwd, b.coeffs.p, b.lde.p, b.cols, b.ncl, c->scale.p, 1, false, b.cm, 0, nz ? &h : nullptr);
     if (nz) column_clean_update(c->stream, nz, b.cols, c->wire_clean.p, true);
   }
   {
@@ -324,12 +334,12 @@ int batch_commit_from_values(p2gpu_circuit *c, Batch &b, const gl_t *vals_dev) {
     // gates): one pass over the witness finds them, and their inverse transform and LDE become stores of zeros
     const uint32_t *nz = batch_colnz(c, b);
     if (nz) {
-      column_flags(c->stream, vals_dev, b.cols, c->d, c->wire_nz.p);
+      column_flags(c->stream, vals_dev, b.cols, c->d, c->sparse_row, c->wire_nz.p, c->wire_scalar.p);
       column_clean_update(c->stream, nz, b.cols, c->wire_clean.p, false);
     }
     gl_t ninv = gl_inv((gl_t)c->n);
-    ntt_batch(c->stream, c->plan_inv, vals_dev, b.coeffs.p, b.cols, 1, nullptr, ninv, false, CosetMap(), 0, nz,
-              nz ? c->wire_clean.p : nullptr);
+    const ColHints h = nz ? wire_hints(c, 0, false) : ColHints();
+    ntt_batch(c->stream, c->plan_inv, vals_dev, b.coeffs.p, b.cols, 1, nullptr, ninv, false, CosetMap(), 0, nz ? &h : nullptr);
   }
   TRACE(c, "  inverse ntt");
   return batch_commit_from_coeffs(c, b);
@@ -531,11 +541,17 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     while (parts < 16 && (n / (parts * 2)) >= 1024) parts *= 2;
     ext_powers_bitrev(st, zeta, d, c->pw.p);
     ext_powers_bitrev(st, gzeta, d, c->pw.p + 2 * n);
-    if (batch_colnz(c, c->wires)) compact_nonzero(st, c->wire_nz.p, c->W, c->wire_nzlist.p);
+    const bool structured = batch_colnz(c, c->wires) != nullptr;
+    const ColHints wh = structured ? wire_hints(c, 0, false) : ColHints();
+    if (structured) {
+      compact_nonzero(st, c->wire_nz.p, c->W, c->wire_nzlist.p);
+      if (c->sparse_coeffs.p) eval_columns(st, c->sparse_coeffs.p, 1, d, c->pw.p, parts, c->sparse_partial.p);
+    }
     size_t base = 0;
     for (int o = 0; o < 4; o++) {
+      const bool hw = structured && oracles[o] == &c->wires;
       eval_columns(st, oracles[o]->coeffs.p, oracles[o]->cols, d, c->pw.p, parts, c->partial.p + base * parts * 2,
-                   batch_colnz(c, *oracles[o]));
+                   hw ? &wh : nullptr, hw ? c->sparse_partial.p : nullptr);
       base += oracles[o]->cols;
     }
     {
@@ -581,8 +597,11 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     gl_t *F0 = c->f01.p, *F1 = c->f01.p + 2 * n;
     uint32_t j0 = 0;
     for (int o = 0; o < 4; o++) {
+      const bool hw = batch_colnz(c, *oracles[o]) != nullptr;
+      const bool unit = hw && c->sparse_coeffs.p != nullptr;
+      if (unit) class1_fold(st, wire_hints(c, 0, false), c->W, c->ext_apow.p, j0, c->sparse_partial.p + 32);
       reduce_columns(st, oracles[o]->coeffs.p, oracles[o]->cols, d, c->ext_apow.p, j0, F0, o != 0,
-                     batch_colnz(c, *oracles[o]) ? c->wire_nzlist.p : nullptr);
+                     hw ? c->wire_nzlist.p : nullptr, unit ? c->sparse_coeffs.p : nullptr, unit ? c->sparse_partial.p + 32 : nullptr);
       j0 += oracles[o]->cols;
     }
     {
@@ -869,6 +888,7 @@ void circuit_release(p2gpu_circuit *c) {
   c->wire_nz.release();
   c->wire_nzlist.release();
   c->wire_clean.release();
+  c->wire_scalar.release(); c->sparse_coeffs.release(); c->sparse_lde.release(); c->sparse_partial.release();
   c->pin.release();
   c->pow_result.release(); c->gather_ptrs.release(); c->gather_out.release(); c->xchg_recv.release();
   ntt_plan_destroy(c->plan_inv);
@@ -1097,6 +1117,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
       }
       if (gi >= c->num_gates) return fail(P2GPU_E_BLOB, "selector column holds an unknown gate index");
       rg[row] = (uint8_t)gi;
+      if (c->sparse_row == UINT32_MAX && c->gates[gi].kind == G_PUBLIC_INPUT) c->sparse_row = (uint32_t)row;
     }
     const uint32_t ngc = c->NC - c->num_selectors;
     CK(c->d_row_gate.alloc(n), "alloc row_gate");
@@ -1120,6 +1141,20 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   CK(c->wire_nzlist.alloc(c->W + 1), "alloc wire flags");
   CK(c->wire_clean.alloc(c->W), "alloc wire flags");
   CK(hipMemsetAsync(c->wire_clean.p, 0, sizeof(uint32_t) * c->W, c->stream), "clear wire flags");
+  CK(c->wire_scalar.alloc(c->W), "alloc wire flags");
+  if (c->sparse_row != UINT32_MAX) {
+    // inverse transform and LDE (all cosets) of the unit column of the PublicInputGate row: what a wire that is
+    // zero everywhere but there transforms to, up to its scalar
+    CK(c->sparse_coeffs.alloc(n), "alloc sparse basis");
+    CK(c->sparse_lde.alloc((size_t)C * n), "alloc sparse basis");
+    CK(c->sparse_partial.alloc(16 * 2 + 2), "alloc sparse basis");
+    const gl_t one = 1;
+    CK(hipMemsetAsync(c->sparse_coeffs.p, 0, 8 * n, st), "sparse basis");
+    CK(hipMemcpyAsync(c->sparse_coeffs.p + c->sparse_row, &one, 8, hipMemcpyHostToDevice, st), "sparse basis");
+    CK(hipStreamSynchronize(st), "sparse basis");  // `one` lives on this stack frame
+    ntt_batch(st, c->plan_inv, c->sparse_coeffs.p, c->sparse_coeffs.p, 1, 1, nullptr, gl_inv((gl_t)n), false);
+    ntt_batch(st, c->plan_fwd, c->sparse_coeffs.p, c->sparse_lde.p, 1, C, c->scale.p, 1, false);
+  }
   CK(c->zp_vals.alloc((size_t)nzp * n), "alloc zp");
   CK(c->cp.alloc((size_t)K * c->nchunks * n), "alloc cp");
   CK(c->rowprod.alloc((size_t)K * n), "alloc rowprod");
@@ -1438,12 +1473,14 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
     const uint32_t *nz = batch_colnz(c, b) ? c->wire_nz.p + col0 : nullptr;
     uint32_t *cl = nz ? c->wire_clean.p + col0 : nullptr;
     if (nz) {
-      column_flags(c->stream, vals, nc, c->d, c->wire_nz.p + col0);
+      column_flags(c->stream, vals, nc, c->d, c->sparse_row, c->wire_nz.p + col0, c->wire_scalar.p + col0);
       column_clean_update(c->stream, nz, nc, cl, false);
     }
-    ntt_batch(c->stream, c->plan_inv, vals, b.coeffs.p + (size_t)col0 * n, nc, 1, nullptr, ninv, false, CosetMap(), 0, nz, cl);
+    const ColHints hi = nz ? wire_hints(c, col0, false) : ColHints(), hl = nz ? wire_hints(c, col0, true) : ColHints();
+    ntt_batch(c->stream, c->plan_inv, vals, b.coeffs.p + (size_t)col0 * n, nc, 1, nullptr, ninv, false, CosetMap(), 0,
+              nz ? &hi : nullptr);
     ntt_batch(c->stream, c->plan_fwd, b.coeffs.p + (size_t)col0 * n, b.lde.p + (size_t)col0 * n, nc, b.ncl, c->scale.p, 1,
-              false, b.cm, W, nz, cl);
+              false, b.cm, W, nz ? &hl : nullptr);
     if (nz) column_clean_update(c->stream, nz, nc, cl, true);
     if (incremental) {
       const bool last = col0 + chunk >= W;

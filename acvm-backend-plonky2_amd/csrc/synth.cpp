@@ -270,8 +270,17 @@ extern "C" {
 // num_wires: 234 = CircuitConfig::wide_ecc_config() (the translator's shape, mod.rs:69), 135 =
 // standard_recursion_config() (used by the reference's memory tests, test_memory_operations.rs:160,389);
 // the custom gates size themselves from it exactly as their `num_ops(config)` do.
+// flags bit 0: randomise only the ROUTED unused wires of the PublicInputGate row (the rest stay zero), so that the
+// row-local generators (N1) reproduce the whole matrix from the routed columns; default (0) = what plonky2's
+// build() does: every wire of that row after the public-inputs hash gets a random value.
+int p2synth_make2(unsigned d, const char *mix, uint64_t seed, uint32_t num_pi, uint32_t num_wires, uint32_t flags,
+                  uint8_t **blob_out, size_t *blob_len, uint64_t **wires_out, uint32_t *num_wires_out, uint64_t *pis_out);
 int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint32_t num_pi, uint32_t num_wires, uint8_t **blob_out,
                  size_t *blob_len, uint64_t **wires_out, uint32_t *num_wires_out, uint64_t *pis_out) {
+  return p2synth_make2(d, mix, seed, num_pi, num_wires, 0, blob_out, blob_len, wires_out, num_wires_out, pis_out);
+}
+int p2synth_make2(unsigned d, const char *mix, uint64_t seed, uint32_t num_pi, uint32_t num_wires, uint32_t flags,
+                  uint8_t **blob_out, size_t *blob_len, uint64_t **wires_out, uint32_t *num_wires_out, uint64_t *pis_out) {
   const uint32_t W = num_wires ? num_wires : 234;
   const uint32_t R = 80, K = 2, QF = 8, RATE_BITS = 3, CAP_H = 4, POW_BITS = 16, QUERIES = 28;
   if (W != 234 && W != 135) return -5;
@@ -435,10 +444,17 @@ int p2synth_make(unsigned d, const char *mix, uint64_t seed, uint32_t num_pi, ui
         else b.connect(Cell{(uint32_t)r, i}, Cell{1, 0});  // hash of no public inputs = constant zero
       }
       // circuit_builder.rs randomize_unused_pi_wires: build() hangs a RandomValueGenerator on every
-      // other wire of this row (visible in the reference's own proofs, tests/golden/reference_proofs.py).
-      // Only the routed ones are randomised here, so that the row-local generators (N1) still
-      // reproduce the full matrix from the routed columns.
+      // other wire of this row, routed or not (visible in the reference's own proofs,
+      // tests/golden/reference_proofs.py: no wire column of a real witness is zero in every row, the unused
+      // ones hold exactly this one value).  The non-routed ones come from a stream of their own, so the rest
+      // of the matrix does not depend on flags bit 0 (routed wires only: what the row-local generators can
+      // rebuild from the routed columns).
       for (uint32_t i = 4; i < R; i++) b.w((uint32_t)r, i) = b.rng.field();
+      if (!(flags & 1)) {
+        Rng extra;
+        extra.s = seed * 0xD1B54A32D192ED03ULL + 0x7654321;
+        for (uint32_t i = R; i < W; i++) b.w((uint32_t)r, i) = extra.field();
+      }
     } else {
       fill_row(b, g, (uint32_t)r, lc);
     }

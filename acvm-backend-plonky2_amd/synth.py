@@ -28,21 +28,24 @@ def _lib():
     return _LIB
 
 
-def make_circuit(degree_bits, mix="arith", seed=1, num_public_inputs=0, num_wires=234, hasher=0):
+def make_circuit(degree_bits, mix="arith", seed=1, num_public_inputs=0, num_wires=234, hasher=0, pi_row_routed_only=False):
     """Returns (blob: np.uint8[...], wires: np.uint64[num_wires][2^degree_bits]) and, when
     num_public_inputs > 0, additionally the public input values (np.uint64[num_public_inputs]).
     num_wires: 234 (wide_ecc_config, the translator's shape) or 135 (standard_recursion_config).
     hasher: 0 = KeccakHash<25> (the reference's KeccakGoldilocksConfig), 1 = PoseidonHash
-    (PoseidonGoldilocksConfig: Poseidon Merkle trees, challenger and circuit digest) -- header word 22."""
+    (PoseidonGoldilocksConfig: Poseidon Merkle trees, challenger and circuit digest) -- header word 22.
+    pi_row_routed_only: the unused NON-routed wires of the PublicInputGate row stay zero instead of holding the
+    random values plonky2's build() gives them (then the routed columns determine the whole matrix)."""
     lib = _lib()
     blob = ctypes.POINTER(ctypes.c_uint8)()
     blen = ctypes.c_size_t()
     wires = ctypes.POINTER(ctypes.c_uint64)()
     nw = ctypes.c_uint32()
     pis = np.zeros(max(num_public_inputs, 1), dtype=np.uint64)
-    rc = lib.p2synth_make(ctypes.c_uint(degree_bits), mix.encode(), ctypes.c_uint64(seed),
-                          ctypes.c_uint32(num_public_inputs), ctypes.c_uint32(num_wires), ctypes.byref(blob), ctypes.byref(blen),
-                          ctypes.byref(wires), ctypes.byref(nw), ctypes.c_void_p(pis.ctypes.data))
+    rc = lib.p2synth_make2(ctypes.c_uint(degree_bits), mix.encode(), ctypes.c_uint64(seed),
+                           ctypes.c_uint32(num_public_inputs), ctypes.c_uint32(num_wires), ctypes.c_uint32(1 if pi_row_routed_only else 0),
+                           ctypes.byref(blob), ctypes.byref(blen),
+                           ctypes.byref(wires), ctypes.byref(nw), ctypes.c_void_p(pis.ctypes.data))
     if rc != 0:
         raise ValueError(f"p2synth_make({degree_bits}, {mix!r}) failed: {rc}")
     try:

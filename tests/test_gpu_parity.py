@@ -136,33 +136,44 @@ def test_proof_bytes_match_oracle(pkg, orc, gpu, d, mix, seed):
     cd.close()
 
 
-@pytest.mark.parametrize("d,mix", [(5, "arith"), (10, "sha"), (13, "sha"), (13, "ecdsa")])
-def test_zero_column_elision_does_not_change_the_proof(pkg, orc, gpu, d, mix):
-    """Wire columns that are zero in every row (the unused wires: 154 of 234 in the sha / arith mixes, as in the
-    reference's circuits without ECC gates) are not transformed -- zeros are stored instead.  Same bytes with the
-    knob off, same bytes as the oracle, on the resident, the chunked host-witness and the routed entry points."""
+@pytest.mark.parametrize("d,mix,routed_only", [(5, "arith", False), (10, "sha", False), (10, "sha", True), (13, "sha", False),
+                                               (13, "arith", True), (13, "ecdsa", False)])
+def test_structured_wire_columns_do_not_change_the_proof(pkg, orc, gpu, d, mix, routed_only):
+    """The wires no gate of a circuit uses (154 of 234 in the sha / arith mixes, as in the reference's circuits
+    without ECC gates) hold ONE value: the random one build() puts in the PublicInputGate row
+    (randomize_unused_pi_wires) -- or nothing at all when a caller leaves them zero.  Their transforms are not
+    computed: zeros are stored / the handle's transform of that row's unit column is scaled.  Same bytes with the
+    knob off, same bytes as the oracle, on the resident and the chunked host-witness entry points."""
     import torch
 
-    blob, wires = pkg.make_circuit(d, mix, 77)
-    nz = int((wires.reshape(234, -1) != 0).any(axis=1).sum())
-    assert nz == 80 if mix != "ecdsa" else nz > 200
+    blob, wires = pkg.make_circuit(d, mix, 77, pi_row_routed_only=routed_only)
+    w = wires.reshape(234, -1)
+    per_col = (w != 0).sum(axis=1)
+    if mix == "ecdsa":
+        assert (per_col > 1).sum() > 200
+    else:
+        assert (per_col > 1).sum() == 80 and (per_col[80:] == (0 if routed_only else 1)).all()
     cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
     expect, _ = oc.prove(wires)
     wd = torch.from_numpy(wires.view(np.int64)).cuda()
     for knob in (1, 0, 1):
         cd.set("zero_columns", knob)
         assert cd.prove(wd).to_bytes() == expect          # p2gpu_prove_dev
-        assert cd.prove(wires).to_bytes() == expect       # p2gpu_prove: column chunks, flags per chunk
-        assert cd.prove_routed(wires[:80]).to_bytes() == expect
-    # a witness whose zero / non-zero pattern changes from proof to proof on the same handle: stale zeros or stale
+        assert cd.prove(wires).to_bytes() == expect       # p2gpu_prove: column chunks, classes per chunk
+        if routed_only:
+            assert cd.prove_routed(wires[:80]).to_bytes() == expect
+    # a witness whose column structure changes from proof to proof on the same handle: stale zeros or stale
     # values of the previous proof must not survive in the coefficient / LDE buffers
     cd.set("self_check", 0)
-    oc2 = oc
-    for cols in ([5, 17, 79], [0, 40], []):
+    pi_row = int(np.nonzero(w[233])[0][0]) if not routed_only and mix != "ecdsa" else 1
+    for cols, rows in (([5, 17, 79, 100], None), ([0, 40, 233], None), ([90, 200], 7), ([], None)):
         w2 = wires.copy()
         for c_ in cols:
-            w2[c_, :] = 0
-        want, _ = oc2.prove(w2)   # an unsatisfied witness still yields (unverifiable) bytes, on both sides
+            if rows is None:
+                w2[c_, :] = 0                       # zero column
+            else:
+                w2[c_, (pi_row + rows) % w.shape[1]] = 5     # a second non-zero row: dense
+        want, _ = oc.prove(w2)   # an unsatisfied witness still yields (unverifiable) bytes, on both sides
         assert cd.prove(torch.from_numpy(w2.view(np.int64)).cuda()).to_bytes() == want, cols
         assert cd.prove(w2).to_bytes() == want, cols
     cd.close()
@@ -187,7 +198,7 @@ def test_public_inputs_proof_bytes_match_oracle(pkg, orc, gpu, d, mix, npi):
 def test_standard_recursion_config_proofs(pkg, orc, gpu, d, mix, npi):
     """135-wire shape (standard_recursion_config): different column counts, gate op counts and
     Keccak block tail than the 234-wire shape."""
-    out = pkg.make_circuit(d, mix, 19, num_public_inputs=npi, num_wires=135)
+    out = pkg.make_circuit(d, mix, 19, num_public_inputs=npi, num_wires=135, pi_row_routed_only=True)
     blob, wires = out[0], out[1]
     pis = out[2] if npi else ()
     cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
@@ -324,7 +335,7 @@ def test_fill_witness_matches_oracle(pkg, orc, gpu, d, mix, npi):
     matrix equals the generator's full witness, and equals the oracle's fill word for word."""
     import torch
 
-    out = pkg.make_circuit(d, mix, 23, num_public_inputs=npi)
+    out = pkg.make_circuit(d, mix, 23, num_public_inputs=npi, pi_row_routed_only=True)
     blob, wires = out[0], out[1]
     pis = out[2] if npi else ()
     cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
@@ -350,7 +361,7 @@ def test_standalone_c_caller(pkg, orc, gpu, tmp_path):
 
     exe = os.path.join(ROOT, "acvm-backend-plonky2_amd", "p2gpu-prove")
     assert os.path.exists(exe)
-    blob, wires, pis = pkg.make_circuit(9, "ecdsa", 29, num_public_inputs=3)
+    blob, wires, pis = pkg.make_circuit(9, "ecdsa", 29, num_public_inputs=3, pi_row_routed_only=True)
     (tmp_path / "c.blob").write_bytes(blob.tobytes())
     (tmp_path / "w.bin").write_bytes(wires.tobytes())
     (tmp_path / "r.bin").write_bytes(np.ascontiguousarray(wires[:80]).tobytes())

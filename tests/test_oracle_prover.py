@@ -144,7 +144,7 @@ def test_fill_witness_row_local_generators(pkg, orc, mix, npi):
     """the gates' own generators (e.g. arithmetic_u32.rs:376-426,
     comparison.rs:439-537) are row-local; from the routed columns alone they rebuild every
     gate-internal column of the witness the generator produced, and the result still proves."""
-    out = pkg.make_circuit(8, mix, 4, num_public_inputs=npi)
+    out = pkg.make_circuit(8, mix, 4, num_public_inputs=npi, pi_row_routed_only=True)
     blob, wires = out[0], out[1]
     pis = out[2] if npi else ()
     oc = orc.OracleCircuit(blob)

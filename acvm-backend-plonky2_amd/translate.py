@@ -317,7 +317,10 @@ class CircuitBuilder:
                 raise ValueError("a wire has no value")
             for (r, c) in cl:
                 wires[c, r] = v
+        # circuit_builder.rs randomize_unused_pi_wires: every wire of the PublicInputGate row after the hash, routed
+        # or not, gets a random value (so no wire column of a real witness is zero in every row)
         wires[4:NUM_ROUTED, pi_row] = self.rng.integers(0, P, size=NUM_ROUTED - 4, dtype=np.uint64)
+        wires[NUM_ROUTED:, pi_row] = self.rng.integers(0, P, size=NUM_WIRES - NUM_ROUTED, dtype=np.uint64)
         self.values = val
         return blob, wires
 

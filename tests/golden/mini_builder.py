@@ -187,7 +187,8 @@ class MiniBuilder:
         for t, cells in cell.items():
             for (r, c) in cells:
                 wires[c, r] = get(t)
-        wires[4:R, pi_row] = self.rng.integers(0, P, size=R - 4, dtype=np.uint64)  # randomize_unused_pi_wires
+        wires[4:R, pi_row] = self.rng.integers(0, P, size=R - 4, dtype=np.uint64)  # randomize_unused_pi_wires:
+        wires[R:, pi_row] = self.rng.integers(0, P, size=W - R, dtype=np.uint64)    # routed or not
         # sigma: classes listed row by row, each cell maps to the next of its class
         classes = {}
         for t, cells in cell.items():

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(1024) void merkle_tail_kernel(dig_t *lvl, uint32_t 
 }
 void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc) {
   if (m <= cap_per) return;
-  ProfScope ps("merkle_tail_kernel", 96.0 * cosets * (double)(m - cap_per));
+  ProfScope ps(prc ? "merkle_tail_kernel<1>" : "merkle_tail_kernel<0>", 96.0 * cosets * (double)(m - cap_per));
   uint32_t threads = m / 2 >= 1024 ? 1024 : (m / 2 >= 64 ? m / 2 : 64);
   if (prc) hipLaunchKernelGGL(merkle_tail_kernel<1>, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per, prc);
   else hipLaunchKernelGGL(merkle_tail_kernel<0>, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per, prc);
@@ -247,7 +247,8 @@ void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32
 void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig, const gl_t *prc) {
   size_t n = (size_t)1 << d;
   uint32_t threads = n >= 256 ? 256 : 64;
-  ProfScope ps("hash_lde_leaves_kernel", (8.0 * cols + 32.0) * cosets * (double)n);
+  // same spelling as rocprofv3's demangled names (<0> Keccak, <1> Poseidon), so the bench line and profiles/ agree
+  ProfScope ps(prc ? "hash_lde_leaves_kernel<1>" : "hash_lde_leaves_kernel<0>", (8.0 * cols + 32.0) * cosets * (double)n);
   if (prc) hipLaunchKernelGGL(hash_lde_leaves_kernel<1>, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc);
   else hipLaunchKernelGGL(hash_lde_leaves_kernel<0>, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc);
 }
@@ -266,14 +267,14 @@ void hash_rows(hipStream_t st, const gl_t *rows, size_t n_rows, uint32_t row_len
 void hash_fri_leaves(hipStream_t st, const gl_t *vals, uint32_t lg_npc, uint32_t cosets, uint32_t ab, dig_t *dig, const gl_t *prc) {
   uint32_t per = (1u << lg_npc) >> ab;
   uint32_t threads = per >= 256 ? 256 : 64;
-  ProfScope ps("hash_fri_leaves_kernel", (16.0 * (1u << ab) + 32.0) * cosets * (double)per);
+  ProfScope ps(prc ? "hash_fri_leaves_kernel<1>" : "hash_fri_leaves_kernel<0>", (16.0 * (1u << ab) + 32.0) * cosets * (double)per);
   if (prc) hipLaunchKernelGGL(hash_fri_leaves_kernel<1>, dim3((per + threads - 1) / threads, cosets), dim3(threads), 0, st, vals, lg_npc, ab, dig, prc);
   else hipLaunchKernelGGL(hash_fri_leaves_kernel<0>, dim3((per + threads - 1) / threads, cosets), dim3(threads), 0, st, vals, lg_npc, ab, dig, prc);
 }
 void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m, const gl_t *prc) {
   uint32_t half = m >> 1;
   uint32_t threads = half >= 256 ? 256 : 64;
-  ProfScope ps("merkle_level_kernel", 96.0 * cosets * (double)half);
+  ProfScope ps(prc ? "merkle_level_kernel<1>" : "merkle_level_kernel<0>", 96.0 * cosets * (double)half);
   if (prc) hipLaunchKernelGGL(merkle_level_kernel<1>, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out, m, prc);
   else hipLaunchKernelGGL(merkle_level_kernel<0>, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out, m, prc);
 }

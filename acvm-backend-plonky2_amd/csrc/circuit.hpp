@@ -221,7 +221,8 @@ struct CircuitState {
                                       // the class 1 columns' joint coefficient in the FRI batch reduction
   DBuf<uint32_t> wire_nzlist;         // [1 + W]: count, then the indices of the non-zero wire columns
   DBuf<uint32_t> wire_clean;          // [W] across proofs: 1 = wires.coeffs / wires.lde of the column hold zeros already
-  int zero_columns = 1;               // knob "zero_columns": elide the transforms of all-zero wire columns
+  int zero_columns = 1;               // knob "zero_columns": do not transform structured wire columns (classes 0 and 1)
+  bool structured_off = false;        // a proof on this handle found every wire column dense: stop classifying
   // tables
   DBuf<gl_t> tw_fwd, tw_inv, scale, inv_scale, d_kis, d_sigmas, fri_scale, qconst;
   DBuf<GateDesc> d_gates;

@@ -96,6 +96,14 @@ void eval_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d,
 // block = 64 positions x 4 column groups: group g sums the columns j = g mod 4 (8 loads in flight
 // per lane), the four partial sums meet in LDS.  (One lane per position alone would be 2 waves per
 // SIMD at n = 2^17, each walking 354 columns with a single load in flight.)
+// LIST = false: every column through direct indices.  LIST = true: only the dense columns of nzlist (nzlist[0] =
+// their number, nzlist[1..] their indices, ascending; scalar loads) -- the zero polynomials add no term, and the
+// class 1 columns (v_j times the unit column's polynomial `basis`) are one term together, sum_j apow_j v_j
+// basis[p], the sum precomputed in fold[2].  Both instantiations are launched when a list exists and the one the
+// batch does not call for returns at once: whether the list pays (fewer than 3/4 of the columns dense) is only
+// known on the device, and one kernel holding both loops needs 66 instead of 46 VGPRs.  The structured columns'
+// coefficients are in memory like anybody's (structured_fill_kernel), so the direct loop is always correct.
+template <bool LIST>
 __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restrict__ coeffs, uint32_t cols, uint32_t d,
                                                              const gl_t *__restrict__ apow, uint32_t j0,
                                                              gl_t *__restrict__ acc, int accumulate,
@@ -105,43 +113,59 @@ __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restr
   const uint32_t n = 1u << d;
   const uint32_t p = blockIdx.x * 64 + threadIdx.x;
   const uint32_t g = threadIdx.y;
+  if (nzlist != nullptr && (nzlist[0] * 4u < cols * 3u) != LIST) return;
   const bool live = p < n;
   gl_t a0 = 0, a1 = 0;
   if (live) {
     Acc160 l0, l1;  // unreduced sums of products (gl.hpp)
     l0.clear();
     l1.clear();
-    // nzlist (optional): nzlist[0] = number of dense columns, nzlist[1..] their indices, ascending -- the zero
-    // polynomials add no term, and the class 1 columns (v_j times the unit column's polynomial `basis`) are one
-    // term together: sum_j apow_j v_j basis[p], the sum precomputed in fold[2]; indices come through scalar loads
-    const uint32_t cnt = nzlist ? nzlist[0] : cols;
-    auto colof = [&](uint32_t i) { return nzlist ? nzlist[1 + i] : i; };
     uint32_t j = g;
+    if constexpr (!LIST) {
 #pragma unroll 1
-    for (; j + 28 < cnt; j += 32) {
-      gl_t v[8];
-      uint32_t cj[8];
+      for (; j + 28 < cols; j += 32) {
+        gl_t v[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        cj[u] = colof(j + 4 * u);
-        v[u] = coeffs[(size_t)cj[u] * n + p];
-      }
+        for (int u = 0; u < 8; u++) v[u] = coeffs[(size_t)(j + 4 * u) * n + p];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        l0.mac(v[u], apow[2 * (j0 + cj[u])]);
-        l1.mac(v[u], apow[2 * (j0 + cj[u]) + 1]);
+        for (int u = 0; u < 8; u++) {
+          l0.mac(v[u], apow[2 * (j0 + j + 4 * u)]);
+          l1.mac(v[u], apow[2 * (j0 + j + 4 * u) + 1]);
+        }
       }
-    }
-    for (; j < cnt; j += 4) {
-      const uint32_t cj = colof(j);
-      const gl_t v = coeffs[(size_t)cj * n + p];
-      l0.mac(v, apow[2 * (j0 + cj)]);
-      l1.mac(v, apow[2 * (j0 + cj) + 1]);
-    }
-    if (basis != nullptr && g == 3) {
-      const gl_t b = basis[p];
-      l0.mac(b, fold[0]);
-      l1.mac(b, fold[1]);
+      for (; j < cols; j += 4) {
+        const gl_t v = coeffs[(size_t)j * n + p];
+        l0.mac(v, apow[2 * (j0 + j)]);
+        l1.mac(v, apow[2 * (j0 + j) + 1]);
+      }
+    } else {
+      const uint32_t cnt = nzlist[0];
+#pragma unroll 1
+      for (; j + 28 < cnt; j += 32) {
+        gl_t v[8];
+        uint32_t cj[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          cj[u] = nzlist[1 + j + 4 * u];
+          v[u] = coeffs[(size_t)cj[u] * n + p];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          l0.mac(v[u], apow[2 * (j0 + cj[u])]);
+          l1.mac(v[u], apow[2 * (j0 + cj[u]) + 1]);
+        }
+      }
+      for (; j < cnt; j += 4) {
+        const uint32_t cj = nzlist[1 + j];
+        const gl_t v = coeffs[(size_t)cj * n + p];
+        l0.mac(v, apow[2 * (j0 + cj)]);
+        l1.mac(v, apow[2 * (j0 + cj) + 1]);
+      }
+      if (basis != nullptr && g == 3) {
+        const gl_t b = basis[p];
+        l0.mac(b, fold[0]);
+        l1.mac(b, fold[1]);
+      }
     }
     a0 = l0.value();
     a1 = l1.value();
@@ -204,8 +228,11 @@ void reduce_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t 
                     gl_t *acc, bool accumulate, const uint32_t *nzlist, const gl_t *basis, const gl_t *fold) {
   uint32_t n = 1u << d;
   ProfScope ps("reduce_columns_kernel", 8.0 * (cols + 4.0) * (double)n);
-  hipLaunchKernelGGL(reduce_columns_kernel, dim3((n + 63) / 64), dim3(64, 4), 0, st, coeffs, cols, d, apow, j0, acc,
+  hipLaunchKernelGGL(reduce_columns_kernel<false>, dim3((n + 63) / 64), dim3(64, 4), 0, st, coeffs, cols, d, apow, j0, acc,
                      accumulate ? 1 : 0, nzlist, basis, fold);
+  if (nzlist)
+    hipLaunchKernelGGL(reduce_columns_kernel<true>, dim3((n + 63) / 64), dim3(64, 4), 0, st, coeffs, cols, d, apow, j0, acc,
+                       accumulate ? 1 : 0, nzlist, basis, fold);
 }
 
 __global__ __launch_bounds__(256) void fri_quotient_values_kernel(const gl_t *F0, const gl_t *F1, uint32_t d,

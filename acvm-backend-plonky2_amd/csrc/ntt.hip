@@ -167,16 +167,8 @@ struct PassArgs {
   uint32_t nrounds;
   uint32_t r[MAX_ROUNDS];       // layers per round, ascending tile bit
   uint32_t tw_off[MAX_ROUNDS];  // offset of the round's table in ptw
-  // structured columns (ColHints, internal.hpp): class 0 = identically zero, 1 = a multiple of the unit column of
-  // one fixed row (`colval` times the precomputed transform `basis` of that unit column), 2 = dense
-  const uint32_t *colnz;        // optional [cols]: the class of every column
-  uint32_t zero_fill;           // this pass writes dst from another buffer: class 0 / 1 columns are written here;
-                                // the in-place passes after it leave them alone
-  const uint32_t *colclean;     // optional [cols]: 1 = dst already holds zeros for this column (an earlier proof on
-                                // the same handle stored them and nothing has written there since): not even stored
-  const gl_t *colval;           // [cols]: the scalar of a class 1 column
-  const gl_t *basis;            // [n] (or [all cosets][n] when basis_per_coset): this transform of the unit column
-  uint32_t basis_per_coset;
+  const uint32_t *colnz;        // optional [cols]: class of every column (ColHints, internal.hpp); only class 2 (dense)
+                                // columns are transformed here, the others are written by structured_fill_kernel
 };
 
 __device__ __forceinline__ uint32_t gidx(uint32_t e, uint32_t hi_base, uint32_t lo0, uint32_t s, uint32_t tb) {
@@ -374,48 +366,10 @@ __global__ __launch_bounds__(TBC ? NTT_THREADS : 256, NTT_MIN_WAVES) void ntt_pa
   const bool glin = (1u << A.tb) <= (uint32_t)NT12;
   const uint32_t g0 = gidx(threadIdx.x, hi_base, lo0, A.s, A.tb), gstep = (NT12 >> (glin ? A.tb : 0)) << A.s;
   const uint32_t l0 = pidx(threadIdx.x);
-  // Zero-column elision: a linear transform maps the zero column to the zero column, whatever the coset.
-  // Circuits of the reference that use no ECC gate leave wires 80..233 of the 234-wire configuration unused
-  // (zero in every row): their blocks store zeros (first pass) or return (in-place passes) -- block-uniform
-  // scalar branch, bit-identical output.
-  const uint32_t cls = A.colnz != nullptr ? A.colnz[col] : 2u;
-  if (cls == 0) {
-    if (A.zero_fill && !(A.colclean != nullptr && A.colclean[col] != 0)) {
-      if constexpr (TBC != 0) {
-#pragma unroll
-        for (int i = 0; i < NTT_PER; i++)
-          dst[glin ? g0 + (uint32_t)i * gstep : gidx(threadIdx.x + i * NT12, hi_base, lo0, A.s, A.tb)] = 0;
-      } else {
-        for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) dst[gidx(e, hi_base, lo0, A.s, A.tb)] = 0;
-      }
-    }
-    return;
-  }
-  if (cls == 1) {
-    // v * (unit column of the fixed row): by linearity its transform is v times the unit column's transform, which
-    // the circuit handle holds -- one product per element instead of the whole network, the same canonical values
-    if (A.zero_fill) {
-      const gl_t v = A.colval[col];
-      const gl_t *bs = A.basis + (A.basis_per_coset ? (size_t)(A.coset_first + coset * A.coset_stride) * n : 0);
-      if constexpr (TBC != 0) {
-        gl_t bv[NTT_PER];
-        uint32_t gi[NTT_PER];
-#pragma unroll
-        for (int i = 0; i < NTT_PER; i++) {
-          gi[i] = glin ? g0 + (uint32_t)i * gstep : gidx(threadIdx.x + i * NT12, hi_base, lo0, A.s, A.tb);
-          bv[i] = bs[gi[i]];
-        }
-#pragma unroll
-        for (int i = 0; i < NTT_PER; i++) dst[gi[i]] = gl_mul(v, bv[i]);
-      } else {
-        for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
-          const uint32_t g = gidx(e, hi_base, lo0, A.s, A.tb);
-          dst[g] = gl_mul(v, bs[g]);
-        }
-      }
-    }
-    return;
-  }
+  // Structured columns (internal.hpp ColHints): a transform is linear, so a zero column maps to zeros and
+  // v * (unit column of the fixed row) to v * (that unit column's transform): structured_fill_kernel wrote them,
+  // nothing to do here (block-uniform scalar branch).
+  if (A.colnz != nullptr && A.colnz[col] != 2u) return;
   if constexpr (TBC != 0) {
     constexpr int PER = NTT_PER, NT = (1 << TBC) / PER;
     static_assert(NT == NT12, "full tile: NTT_THREADS lanes");
@@ -591,9 +545,36 @@ void ntt_plan_destroy(NttPlan *p) {
   delete p;
 }
 
+// The whole transform of the structured columns of a batch (ColHints): class 0 -> zeros (not even stored when the
+// column's clean mark says dst holds them already), class 1 -> val[c] * basis.  One lane per 2 elements, coalesced;
+// blocks of dense columns return at once.  By linearity these are the canonical values the butterfly network
+// would produce.
+__global__ __launch_bounds__(256) void structured_fill_kernel(gl_t *dst, uint32_t d, uint32_t col_stride, uint32_t cosets,
+                                                              ColHints h, uint32_t coset_first, uint32_t coset_stride) {
+  const uint32_t col = blockIdx.y;
+  const uint32_t cls = h.cls[col];
+  if (cls == 2u) return;
+  if (cls == 0u && h.clean != nullptr && h.clean[col] != 0u) return;
+  const size_t n = (size_t)1 << d;
+  const gl_t v = cls == 1u ? h.val[col] : 0;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (uint32_t coset = 0; coset < cosets; coset++) {  // one block covers its slice of every coset: 8x fewer blocks to retire
+    gl_t *out = dst + ((size_t)coset * col_stride + col) * n;
+    const gl_t *bs = h.basis + (h.basis_per_coset ? (size_t)(coset_first + coset * coset_stride) * n : 0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) out[i] = cls == 1u ? gl_mul(v, bs[i]) : (gl_t)0;
+  }
+}
+
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
                const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_cols, const ColHints *hints) {
   if (cols == 0) return;
+  if (hints) {
+    const size_t n = (size_t)1 << plan->d;
+    const uint32_t bx = (uint32_t)std::max<size_t>(1, n / (256 * 4));
+    ProfScope ps("structured_fill_kernel", 8.0 * cols * cosets * (double)n);
+    hipLaunchKernelGGL(structured_fill_kernel, dim3(bx, cols), dim3(256), 0, st, dst, plan->d,
+                       stride_cols ? stride_cols : cols, cosets, *hints, cm.first, cm.stride);
+  }
   const uint32_t d = plan->d;
   const size_t np = plan->passes.size();
   for (size_t i = 0; i < np; i++) {
@@ -612,11 +593,6 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     A.coset_stride = cm.stride;
     A.nrounds = ps.nrounds;
     A.colnz = hints ? hints->cls : nullptr;
-    A.colclean = hints ? hints->clean : nullptr;
-    A.colval = hints ? hints->val : nullptr;
-    A.basis = hints ? hints->basis : nullptr;
-    A.basis_per_coset = hints && hints->basis_per_coset ? 1 : 0;
-    A.zero_fill = (i == 0) ? 1 : 0;
     for (int k = 0; k < MAX_ROUNDS; k++) { A.r[k] = ps.r[k]; A.tw_off[k] = ps.tw_off[k]; }
     const uint32_t TB = A.a + A.tb;
     const uint32_t tiles = 1u << (d - TB);

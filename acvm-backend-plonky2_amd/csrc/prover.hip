@@ -567,9 +567,10 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     HIP_TRY(hipStreamSynchronize(st));
     g_hp.mark("WAIT(openings)");
     // Which wires a circuit leaves unused does not change from proof to proof.  A handle whose witness turned
-    // out fully dense stops looking (the class pass over the witness and the fill launches are ~0.1 ms at 2^20
-    // rows for nothing); the knob "zero_columns" = 1 makes it look again.
-    if (dense_count && *dense_count == c->W) c->structured_off = true;
+    // out (almost) fully dense stops looking: the class pass over the witness and the fill launches cost ~0.1 ms
+    // at 2^20 rows, what fewer than 5 % structured columns give back; the knob "zero_columns" = 1 makes it look
+    // again.  (Every column is then transformed like a dense one, which is always correct.)
+    if (dense_count && (uint64_t)(c->W - *dense_count) * 20u < c->W) c->structured_off = true;
     for (size_t j = 0; j < nall + K; j++) {
       gl_t a0 = 0, a1 = 0;
       for (uint32_t p = 0; p < parts; p++) {

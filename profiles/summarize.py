@@ -23,9 +23,15 @@ def short(name):
     return n.strip()
 
 
+def newest(paths):
+    return sorted(paths, key=os.path.getmtime)[-1:]
+
+
 def counter_avgs(d, counter):
     acc = defaultdict(lambda: [0.0, 0])
-    for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+    # gpurun MERGES a call's files into gpurun_out/: a tag profiled twice leaves both runs' CSVs side by side
+    # (the pid is in the file name) -- only the newest run counts
+    for path in newest(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)):
         with open(path) as f:
             for row in csv.DictReader(f):
                 if row["Counter_Name"] != counter:
@@ -42,7 +48,7 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     stats = glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True)
     if stats:
-        shutil.copy(stats[0], os.path.join(here, f"{tag}_kernel_stats.csv"))
+        shutil.copy(newest(stats)[0], os.path.join(here, f"{tag}_kernel_stats.csv"))
     fetch = counter_avgs(os.path.join(src, "fetch"), "FETCH_SIZE")
     write = counter_avgs(os.path.join(src, "write"), "WRITE_SIZE")
     out = {}

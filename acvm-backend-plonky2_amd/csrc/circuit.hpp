@@ -223,6 +223,8 @@ struct CircuitState {
   DBuf<uint32_t> wire_clean;          // [W] across proofs: 1 = wires.coeffs / wires.lde of the column hold zeros already
   int zero_columns = 1;               // knob "zero_columns": do not transform structured wire columns (classes 0 and 1)
   bool structured_off = false;        // a proof on this handle found every wire column dense: stop classifying
+  uint32_t gate_wires = 0;            // wires [0, gate_wires) are what the gates of the circuit can read (max over the gate table)
+  int virtual_columns = 1;            // knob "virtual_columns": structured columns >= max(R, gate_wires) get no LDE in memory (VirtCols)
   // tables
   DBuf<gl_t> tw_fwd, tw_inv, scale, inv_scale, d_kis, d_sigmas, fri_scale, qconst;
   DBuf<GateDesc> d_gates;

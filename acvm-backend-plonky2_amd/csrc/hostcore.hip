@@ -173,6 +173,7 @@ int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off
   size_t off = 256;
   if (len < off + (size_t)c->num_gates * 48) return fail(P2GPU_E_BLOB, "blob truncated (gate table)");
   c->max_gate_constraints = 0;
+  c->gate_wires = 0;
   c->gates.clear();
   for (uint32_t i = 0; i < c->num_gates; i++) {
     uint32_t g[12];
@@ -195,6 +196,7 @@ int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off
     if (G.sel_index >= c->num_selectors || G.group_end > c->num_gates || G.group_start > i || i >= G.group_end)
       return fail(P2GPU_E_BLOB, "bad selector info");
     c->max_gate_constraints = std::max(c->max_gate_constraints, G.num_constraints);
+    c->gate_wires = std::max(c->gate_wires, (uint32_t)wires_used);
     c->gates.push_back(G);
   }
   *cap_in = nullptr;

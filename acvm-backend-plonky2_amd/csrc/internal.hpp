@@ -56,6 +56,8 @@ struct ColHints {
   const gl_t *val = nullptr;        // [cols]: scalar of the class 1 columns
   const gl_t *basis = nullptr;      // this transform of the unit column: [n], or [all cosets][n] (indexed by GLOBAL coset)
   bool basis_per_coset = false;
+  uint32_t virt_first = UINT32_MAX; // columns >= virt_first (relative to cls) of class 0 / 1 are not stored at all: their
+                                    // consumers recompute val[c] * basis on the fly (VirtCols)
 };
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
                const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm = CosetMap(), uint32_t stride_cols = 0,
@@ -73,9 +75,20 @@ void bitrev_cols(hipStream_t st, const gl_t *in, gl_t *out, uint32_t d, uint32_t
 void field_selftest(hipStream_t st, const uint64_t *a, const uint64_t *b, uint32_t n, unsigned long long *bad);
 
 // ---- merkle.hip ----
+// Wire columns whose LDE is never written to memory: a class 0 / class 1 column (ColHints) that no gate and no
+// permutation check reads is, on every LDE row, val[c] * basis[coset][k] -- one modular product in the leaf hash
+// (and in the query gather) instead of 8 bytes written by the fill kernel and 8 bytes read back by the hash.
+struct VirtCols {
+  const uint32_t *cls = nullptr;  // [cols] classes of the proof in progress; nullptr: nothing is virtual
+  const gl_t *val = nullptr;      // [cols] scalars of the class 1 columns
+  const gl_t *basis = nullptr;    // LDE of the unit column, [all cosets][n] indexed by GLOBAL coset (nullptr: no class 1 exists)
+  uint32_t first = UINT32_MAX;    // columns >= first whose class is not 2 are virtual
+  uint32_t coset_first = 0, coset_stride = 1;
+};
 // leaf digests of an LDE batch: lde [cosets][cols][n] -> dig [cosets][n]
 // prc: the handle's Poseidon round constants in device memory selects PoseidonHash; nullptr = KeccakHash<25>
-void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig, const gl_t *prc = nullptr);
+void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig, const gl_t *prc = nullptr,
+                     const VirtCols *virt = nullptr);
 // row-major rows (stage-level operator)
 void hash_rows(hipStream_t st, const gl_t *rows, size_t n_rows, uint32_t row_len, dig_t *dig);
 // FRI step leaves: vals [cosets][2][npc] (ext coordinates), leaf = 16 ext values; dig [cosets][npc/16]
@@ -85,7 +98,7 @@ void hash_fri_leaves(hipStream_t st, const gl_t *vals, uint32_t lg_npc, uint32_t
 // incremental variant: absorb the rate blocks [blk0, blk0 + nblk) (17 columns each) into the sponge
 // states kept in `state` ([cosets][25][n]); `last` also absorbs the tail + padding and writes digests
 void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, uint32_t blk0,
-                     uint32_t nblk, bool first, bool last, uint64_t *state, dig_t *dig);
+                     uint32_t nblk, bool first, bool last, uint64_t *state, dig_t *dig, const VirtCols *virt = nullptr);
 void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m, const gl_t *prc = nullptr);
 // every level below one with m <= 4096 nodes per coset, down to cap_per nodes per coset, in one launch
 void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc = nullptr);

@@ -66,7 +66,7 @@ __device__ __forceinline__ dig_t node_hash(const dig_t &l, const dig_t &r, const
   else return keccak_two_to_one(l, r);
 }
 
-template <class F>
+template <bool PREFETCH = true, class F>
 __device__ __forceinline__ dig_t sponge_hash(uint32_t nwords, F get) {
   uint64_t st[25];
 #pragma unroll
@@ -74,21 +74,30 @@ __device__ __forceinline__ dig_t sponge_hash(uint32_t nwords, F get) {
   uint32_t off = 0;
   // software pipeline: the 17 words of block b+1 are requested before Keccak-f runs on block b,
   // so the loads (one 512 B wave access per column) fly under ~4300 VALU instructions
-  uint64_t nxt[17];
-  const bool first_full = nwords >= 17;
-  if (first_full) {
+  if constexpr (PREFETCH) {
+    uint64_t nxt[17];
+    const bool first_full = nwords >= 17;
+    if (first_full) {
 #pragma unroll
-    for (int w = 0; w < 17; w++) nxt[w] = get(w);
-  }
-  while (nwords - off >= 17) {
-#pragma unroll
-    for (int w = 0; w < 17; w++) st[w] ^= nxt[w];
-    off += 17;
-    if (nwords - off >= 17) {
-#pragma unroll
-      for (int w = 0; w < 17; w++) nxt[w] = get(off + w);
+      for (int w = 0; w < 17; w++) nxt[w] = get(w);
     }
-    keccak_f1600(st);
+    while (nwords - off >= 17) {
+#pragma unroll
+      for (int w = 0; w < 17; w++) st[w] ^= nxt[w];
+      off += 17;
+      if (nwords - off >= 17) {
+#pragma unroll
+        for (int w = 0; w < 17; w++) nxt[w] = get(off + w);
+      }
+      keccak_f1600(st);
+    }
+  } else {
+    while (nwords - off >= 17) {
+#pragma unroll
+      for (int w = 0; w < 17; w++) st[w] ^= get(off + w);
+      off += 17;
+      keccak_f1600(st);
+    }
   }
   const uint32_t rem = nwords - off;
 #pragma unroll
@@ -102,7 +111,7 @@ __device__ __forceinline__ dig_t sponge_hash(uint32_t nwords, F get) {
 }
 
 // hash_or_noop: rows of <= 3 elements (Keccak: 25 bytes) / <= 4 elements (Poseidon: a HashOut) are copied
-template <int H = 0, class F>
+template <int H = 0, bool PREFETCH = true, class F>
 __device__ __forceinline__ dig_t hash_or_noop(uint32_t nwords, F get, const gl_t *prc = nullptr) {
   if constexpr (H == 1) {
     if (nwords <= 4) {
@@ -123,21 +132,47 @@ __device__ __forceinline__ dig_t hash_or_noop(uint32_t nwords, F get, const gl_t
     d.w[3] = 0;
     return d;
   }
-  return sponge_hash(nwords, get);
+  return sponge_hash<PREFETCH>(nwords, get);
 }
 
 #ifndef P2_LEAF_WAVES
 #define P2_LEAF_WAVES 1
 #endif
-template <int H>
-__global__ __launch_bounds__(256, P2_LEAF_WAVES) void hash_lde_leaves_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
-                                                              dig_t *__restrict__ dig, const gl_t *__restrict__ prc) {
+// The variant with unmaterialised columns absorbs without the prefetch array (most of its words are computed, not
+// loaded): 97 VGPRs, 4 waves per SIMD, no scratch.  Measured at 2^20 rows (wires tree, 154 virtual columns): 1.64 ms
+// either way with 4 waves (with the prefetch: 128 VGPRs + 20 B of scratch), 1.73 ms unbounded (131 VGPRs, 3 waves),
+// 1.64 ms at 5 waves (96 VGPRs + 12 B of scratch) -- the kernel sits at the issue ceiling, not at a latency.
+#ifndef P2_LEAFV_WAVES
+#define P2_LEAFV_WAVES 4
+#endif
+#ifndef P2_LEAFV_PREFETCH
+#define P2_LEAFV_PREFETCH 0
+#endif
+// value of column i on this lane's LDE row: read from memory, or -- for a virtual column (VirtCols) -- the
+// product of the column's scalar with the unit column's LDE value Lk of the row.  The branch is wave-uniform
+// (class and scalar come through scalar loads); gl_mul returns the canonical value the fill kernel would have
+// stored, so the digest is the same.
+__device__ __forceinline__ gl_t virt_get(const VirtCols &v, uint32_t i, gl_t Lk, const gl_t *base, size_t n) {
+  if (i >= v.first) {
+    const uint32_t cl = v.cls[i];
+    if (cl != 2u) return cl == 1u ? gl_mul(v.val[i], Lk) : (gl_t)0;
+  }
+  return base[(size_t)i * n];
+}
+template <int H, bool V>
+__global__ __launch_bounds__(256, V ? P2_LEAFV_WAVES : P2_LEAF_WAVES) void hash_lde_leaves_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
+                                                              dig_t *__restrict__ dig, const gl_t *__restrict__ prc, const VirtCols v) {
   const size_t n = (size_t)1 << d;
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t c = blockIdx.y;
   if (k >= n) return;
   const gl_t *base = lde + (size_t)c * cols * n + k;
-  dig[(size_t)c * n + k] = hash_or_noop<H>(cols, [&](uint32_t i) { return base[(size_t)i * n]; }, prc);
+  if constexpr (V) {
+    const gl_t Lk = v.basis ? v.basis[(size_t)(v.coset_first + c * v.coset_stride) * n + k] : (gl_t)0;
+    dig[(size_t)c * n + k] = hash_or_noop<H, P2_LEAFV_PREFETCH != 0>(cols, [&](uint32_t i) { return virt_get(v, i, Lk, base, n); }, prc);
+  } else {
+    dig[(size_t)c * n + k] = hash_or_noop<H>(cols, [&](uint32_t i) { return base[(size_t)i * n]; }, prc);
+  }
 }
 
 // Leaf hashing for a witness that arrives in column chunks (p2gpu_prove): a Keccak sponge absorbs
@@ -145,30 +180,36 @@ __global__ __launch_bounds__(256, P2_LEAF_WAVES) void hash_lde_leaves_kernel(con
 // device can be absorbed while later columns are still crossing PCIe.  The 25-word state of every
 // row waits in HBM between calls ([coset][25][n], word-major: coalesced); the call with `last` also
 // absorbs the ragged tail with the padding and writes the digest.
+template <bool V>
 __global__ __launch_bounds__(256) void hash_lde_absorb_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
                                                               uint32_t blk0, uint32_t nblk, int first, int last,
-                                                              uint64_t *__restrict__ state, dig_t *__restrict__ dig) {
+                                                              uint64_t *__restrict__ state, dig_t *__restrict__ dig, const VirtCols v) {
   const size_t n = (size_t)1 << d;
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t c = blockIdx.y;
   if (k >= n) return;
   const gl_t *base = lde + (size_t)c * cols * n + k;
   uint64_t *sp = state + (size_t)c * 25 * n + k;
+  gl_t Lk = 0;
+  if constexpr (V) Lk = v.basis ? v.basis[(size_t)(v.coset_first + c * v.coset_stride) * n + k] : (gl_t)0;
+  auto get = [&](uint32_t i) -> gl_t {
+    if constexpr (V) return virt_get(v, i, Lk, base, n);
+    else return base[(size_t)i * n];
+  };
   uint64_t st[25];
 #pragma unroll
   for (int i = 0; i < 25; i++) st[i] = first ? 0 : sp[(size_t)i * n];
   for (uint32_t b = 0; b < nblk; b++) {
-    const gl_t *col = base + (size_t)17 * (blk0 + b) * n;
+    const uint32_t i0 = 17 * (blk0 + b);
 #pragma unroll
-    for (int w = 0; w < 17; w++) st[w] ^= col[(size_t)w * n];
+    for (int w = 0; w < 17; w++) st[w] ^= get(i0 + w);
     keccak_f1600(st);
   }
   if (last) {
     const uint32_t off = 17 * (blk0 + nblk), rem = cols - off;  // rem < 17
-    const gl_t *col = base + (size_t)off * n;
 #pragma unroll
     for (int w = 0; w < 17; w++) {
-      if ((uint32_t)w < rem) st[w] ^= col[(size_t)w * n];
+      if ((uint32_t)w < rem) st[w] ^= get(off + w);
       if ((uint32_t)w == rem) st[w] ^= 0x01ULL;
     }
     st[16] ^= 0x8000000000000000ULL;
@@ -244,22 +285,33 @@ void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32
   else hipLaunchKernelGGL(merkle_tail_kernel<0>, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per, prc);
 }
 
-void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig, const gl_t *prc) {
+void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig, const gl_t *prc,
+                     const VirtCols *virt) {
   size_t n = (size_t)1 << d;
   uint32_t threads = n >= 256 ? 256 : 64;
+  if (virt && virt->cls && virt->first < cols) {  // the wires of a proof with unmaterialised columns (same digests)
+    ProfScope ps(prc ? "hash_lde_leaves_kernel<1, true>" : "hash_lde_leaves_kernel<0, true>", (8.0 * cols + 32.0) * cosets * (double)n);
+    if (prc) hipLaunchKernelGGL((hash_lde_leaves_kernel<1, true>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, *virt);
+    else hipLaunchKernelGGL((hash_lde_leaves_kernel<0, true>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, *virt);
+    return;
+  }
   // same spelling as rocprofv3's demangled names (<0> Keccak, <1> Poseidon), so the bench line and profiles/ agree
-  ProfScope ps(prc ? "hash_lde_leaves_kernel<1>" : "hash_lde_leaves_kernel<0>", (8.0 * cols + 32.0) * cosets * (double)n);
-  if (prc) hipLaunchKernelGGL(hash_lde_leaves_kernel<1>, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc);
-  else hipLaunchKernelGGL(hash_lde_leaves_kernel<0>, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc);
+  ProfScope ps(prc ? "hash_lde_leaves_kernel<1, false>" : "hash_lde_leaves_kernel<0, false>", (8.0 * cols + 32.0) * cosets * (double)n);
+  if (prc) hipLaunchKernelGGL((hash_lde_leaves_kernel<1, false>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, VirtCols());
+  else hipLaunchKernelGGL((hash_lde_leaves_kernel<0, false>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, VirtCols());
 }
 void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, uint32_t blk0,
-                     uint32_t nblk, bool first, bool last, uint64_t *state, dig_t *dig) {
+                     uint32_t nblk, bool first, bool last, uint64_t *state, dig_t *dig, const VirtCols *virt) {
   size_t n = (size_t)1 << d;
   uint32_t threads = n >= 256 ? 256 : 64;
   ProfScope ps("hash_lde_absorb_kernel", (8.0 * 17 * nblk + (first ? 0 : 200) + (last ? 32 + 8.0 * (cols - 17 * (blk0 + nblk)) : 200)) *
                                              cosets * (double)n);
-  hipLaunchKernelGGL(hash_lde_absorb_kernel, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols,
-                     d, blk0, nblk, first ? 1 : 0, last ? 1 : 0, state, dig);
+  if (virt && virt->cls && virt->first < cols)
+    hipLaunchKernelGGL(hash_lde_absorb_kernel<true>, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols,
+                       d, blk0, nblk, first ? 1 : 0, last ? 1 : 0, state, dig, *virt);
+  else
+    hipLaunchKernelGGL(hash_lde_absorb_kernel<false>, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols,
+                       d, blk0, nblk, first ? 1 : 0, last ? 1 : 0, state, dig, VirtCols());
 }
 void hash_rows(hipStream_t st, const gl_t *rows, size_t n_rows, uint32_t row_len, dig_t *dig) {
   hipLaunchKernelGGL(hash_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, st, rows, n_rows, row_len, dig);

@@ -554,6 +554,7 @@ __global__ __launch_bounds__(256) void structured_fill_kernel(gl_t *dst, uint32_
   const uint32_t col = blockIdx.y;
   const uint32_t cls = h.cls[col];
   if (cls == 2u) return;
+  if (col >= h.virt_first) return;  // never read from memory: the leaf hash and the query gather recompute it
   if (cls == 0u && h.clean != nullptr && h.clean[col] != 0u) return;
   const size_t n = (size_t)1 << d;
   const gl_t v = cls == 1u ? h.val[col] : 0;

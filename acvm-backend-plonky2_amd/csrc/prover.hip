@@ -298,6 +298,14 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
 const uint32_t *batch_colnz(const p2gpu_circuit *c, const Batch &b) {
   return (&b == &c->wires && c->zero_columns && !c->structured_off && c->wire_nz.p) ? c->wire_nz.p : nullptr;
 }
+// First wire column whose LDE is not materialised when it is structured (class 0 / 1): no gate reads a wire >=
+// gate_wires and the permutation argument stops at R, so the only readers of those LDE columns are the leaf hash
+// and the query gather, which recompute val * LDE(unit column) instead (VirtCols).  UINT32_MAX: off.
+uint32_t virt_first(const p2gpu_circuit *c) {
+  if (!c->virtual_columns || !batch_colnz(c, c->wires)) return UINT32_MAX;
+  const uint32_t f = std::max(c->R, c->gate_wires);
+  return f < c->W ? f : UINT32_MAX;
+}
 // hints for the transforms of the wire columns [col0, ...): lde = false: values -> coefficients, true: the LDE
 ColHints wire_hints(const p2gpu_circuit *c, uint32_t col0, bool lde) {
   ColHints h;
@@ -306,7 +314,22 @@ ColHints wire_hints(const p2gpu_circuit *c, uint32_t col0, bool lde) {
   h.val = c->wire_scalar.p + col0;
   h.basis = lde ? c->sparse_lde.p : c->sparse_coeffs.p;
   h.basis_per_coset = lde;
+  const uint32_t vf = virt_first(c);
+  if (lde && vf != UINT32_MAX) h.virt_first = vf > col0 ? vf - col0 : 0;
   return h;
+}
+// the unmaterialised columns of batch b for its leaf hash (only the wires have any)
+VirtCols batch_virt(const p2gpu_circuit *c, const Batch &b) {
+  VirtCols v;
+  const uint32_t vf = &b == &c->wires ? virt_first(c) : UINT32_MAX;
+  if (vf == UINT32_MAX) return v;
+  v.cls = c->wire_nz.p;
+  v.val = c->wire_scalar.p;
+  v.basis = c->sparse_lde.p;
+  v.first = vf;
+  v.coset_first = b.cm.first;
+  v.coset_stride = b.cm.stride;
+  return v;
 }
 int batch_commit_from_coeffs(p2gpu_circuit *c, Batch &b) {
   {
@@ -316,14 +339,16 @@ int batch_commit_from_coeffs(p2gpu_circuit *c, Batch &b) {
     if (nz) column_clean_update(c->stream, nz, b.cols, c->wire_clean.p, true);
   }
   {
-    hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p, hprc(c));
+    const VirtCols v = batch_virt(c, b);
+    hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p, hprc(c), &v);
   }
   TRACE(c, "  lde + leaf hash");
   return tree_build(c, b, c->n);
 }
 // hash + tree of a batch whose LDE is already in place
 int batch_commit_from_lde(p2gpu_circuit *c, Batch &b) {
-  hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p, hprc(c));
+  const VirtCols v = batch_virt(c, b);
+  hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p, hprc(c), &v);
   TRACE(c, "  leaf hash");
   return tree_build(c, b, c->n);
 }
@@ -419,6 +444,11 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
 
   c->pin.reset();
   use_hasher(c);
+  // which structured wire columns go without an LDE in memory is fixed here for the whole proof (structured_off may
+  // flip at the openings; the query gather must see what the commitment saw)
+  const uint32_t vfirst = virt_first(c);
+  const uint32_t *h_cls = nullptr;  // host copies of the column classes / scalars (read back with the openings)
+  const gl_t *h_val = nullptr;
   // ---- 1. wires commitment ----
   g_hp.mark("start");
   TRACE(c, "enter");
@@ -563,6 +593,15 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     HIP_TRY(hipMemcpyAsync(part, c->partial.p, npart * 8, hipMemcpyDeviceToHost, st));
     uint32_t *dense_count = structured ? c->pin.take<uint32_t>(1) : nullptr;
     if (dense_count) HIP_TRY(hipMemcpyAsync(dense_count, c->wire_nzlist.p, 4, hipMemcpyDeviceToHost, st));
+    if (vfirst != UINT32_MAX) {
+      uint32_t *hc = c->pin.take<uint32_t>(W);
+      gl_t *hv = c->pin.take<gl_t>(W);
+      if (!hc || !hv) return pin_exhausted();
+      HIP_TRY(hipMemcpyAsync(hc, c->wire_nz.p, 4 * (size_t)W, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(hv, c->wire_scalar.p, 8 * (size_t)W, hipMemcpyDeviceToHost, st));
+      h_cls = hc;
+      h_val = hv;
+    }
     g_hp.mark("enq(openings)");
     HIP_TRY(hipStreamSynchronize(st));
     g_hp.mark("WAIT(openings)");
@@ -743,6 +782,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   std::vector<size_t> pos;
   const int world = c->shard_world, me = c->shard_rank;
   size_t per_query = 0;
+  std::vector<std::pair<size_t, uint32_t>> virt_fix;  // (slot of the gather, wire column): slot holds LDE(unit column), wants val * it
   for (size_t x : qidx) {
     // every piece of query x lives in coset r = bitrev(top bits of x): one rank owns the query
     const uint32_t rq = brev((uint32_t)(x >> d), lgC);
@@ -752,8 +792,16 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
       const Batch &b = *oracles[o];
       const uint32_t r = rq, k = brev((uint32_t)(x & (n - 1)), d);
       const uint32_t z = (r - b.cm.first) / b.cm.stride;
-      for (uint32_t col = 0; col < b.cols; col++)
+      for (uint32_t col = 0; col < b.cols; col++) {
+        if (o == 1 && col >= vfirst && h_cls[col] != 2u) {
+          // unmaterialised column: class 0 opens to 0, class 1 to val * LDE(unit column)[r][k] (product taken on the host)
+          const bool c1 = h_cls[col] == 1u && c->sparse_lde.p;
+          if (c1) virt_fix.emplace_back(ptrs.size(), col);
+          ptrs.push_back(c1 && mine ? (uint64_t)(uintptr_t)(c->sparse_lde.p + (size_t)r * n + k) : 0);
+          continue;
+        }
         ptrs.push_back(mine ? (uint64_t)(uintptr_t)(b.lde.p + ((size_t)z * b.cols + col) * n + k) : 0);
+      }
       pos.clear();
       if (mine) path_positions(b, C, lgC, n, d, x, pos);
       else pos.assign(b.level_off.size() - 1, 0);
@@ -819,6 +867,8 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
       memcpy(&gathered[qi * per_query], &all[(size_t)owner * ptrs.size() + qi * per_query], per_query * 8);
     }
   }
+
+  for (auto &f : virt_fix) gathered[f.first] = gl_mul(h_val[f.second], gathered[f.first]);
 
   // ---- serialise: plonky2 ProofWithPublicInputs::to_bytes ----
   Buf out;
@@ -1215,7 +1265,8 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   {
     size_t n_final = n;
     for (uint32_t s = 0; s < c->n_steps; s++) n_final >>= c->arity[s];
-    CK(c->pin.alloc(16 * c->gather_cap + 32 * n_final + 16 * (size_t)(nall + K) * 16 + ((size_t)1 << 18)), "alloc pinned staging");
+    CK(c->pin.alloc(16 * c->gather_cap + 32 * n_final + 16 * (size_t)(nall + K) * 16 + 16 * (size_t)c->nterms + 16 * (size_t)c->W + ((size_t)1 << 18)),
+       "alloc pinned staging");
   }
 
   mark("batch + work buffer allocation");
@@ -1275,6 +1326,11 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
   if (k == "pow_hint") c->pow_hint = value;
   else if (k == "self_check") c->self_check = (int)value;
   else if (k == "shard_exercise") c->shard_exercise = (int)value;
+  else if (k == "virtual_columns") {
+    c->virtual_columns = (int)value;
+    // a clean mark set while the knob was on vouches for the coefficients only (the LDE was never written): forget them
+    if (c->wire_clean.p) HIP_TRY(hipMemsetAsync(c->wire_clean.p, 0, sizeof(uint32_t) * c->W, c->stream));
+  }
   else if (k == "zero_columns") {
     c->zero_columns = (int)value;
     c->structured_off = false;
@@ -1494,7 +1550,8 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
       const bool last = col0 + chunk >= W;
       const uint32_t blk0 = col0 / 17;
       const uint32_t nblk = last ? full_blocks - blk0 : chunk / 17;
-      hash_lde_absorb(c->stream, b.lde.p, W, c->d, b.ncl, blk0, nblk, col0 == 0, last, c->hash_state.p, b.dig.p);
+      const VirtCols v = batch_virt(c, b);
+      hash_lde_absorb(c->stream, b.lde.p, W, c->d, b.ncl, blk0, nblk, col0 == 0, last, c->hash_state.p, b.dig.p, &v);
     }
   }
   const double h2d = now_ms() - t0;  // host time spent feeding PCIe (the transforms overlap with it)

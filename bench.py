@@ -260,6 +260,9 @@ def main():
         pis = made[2] if args.public_inputs else ()
     S = 1 if sharded else max(1, min(args.in_flight, args.steps, 1 if d >= 21 else (2 if d == 20 else 8)))
     cds = [pkg.CircuitData(blob) for _ in range(S)]
+    if os.environ.get("P2GPU_BENCH_NO_SELF_CHECK"):  # kernel-timing experiments with deliberately wrong kernels (scratch/) only
+        for cd_ in cds:
+            cd_.set("self_check", 0)
     if args.mode == "sharded":
         # world 1: same code path as a replica (nothing to exchange); world > 1: RCCL inside the library
         cds[0].set_shard(rank, world, transport="rccl" if args.backend == "nccl" else None)

@@ -156,8 +156,11 @@ def test_structured_wire_columns_do_not_change_the_proof(pkg, orc, gpu, d, mix, 
     cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
     expect, _ = oc.prove(wires)
     wd = torch.from_numpy(wires.view(np.int64)).cuda()
-    for knob in (1, 0, 1):
+    # "virtual_columns": structured columns that no gate reads get no LDE in memory at all -- the leaf hash and the
+    # query gather recompute val * LDE(unit column); toggling it between proofs must not leave stale buffers behind
+    for knob, virt in ((1, 1), (1, 0), (0, 1), (1, 1), (1, 0)):
         cd.set("zero_columns", knob)
+        cd.set("virtual_columns", virt)
         assert cd.prove(wd).to_bytes() == expect          # p2gpu_prove_dev
         assert cd.prove(wires).to_bytes() == expect       # p2gpu_prove: column chunks, classes per chunk
         if routed_only:
@@ -174,8 +177,13 @@ def test_structured_wire_columns_do_not_change_the_proof(pkg, orc, gpu, d, mix, 
             else:
                 w2[c_, (pi_row + rows) % w.shape[1]] = 5     # a second non-zero row: dense
         want, _ = oc.prove(w2)   # an unsatisfied witness still yields (unverifiable) bytes, on both sides
+        cd.set("virtual_columns", 1)
         assert cd.prove(torch.from_numpy(w2.view(np.int64)).cuda()).to_bytes() == want, cols
         assert cd.prove(w2).to_bytes() == want, cols
+        cd.set("virtual_columns", 0)
+        assert cd.prove(w2).to_bytes() == want, cols
+        cd.set("virtual_columns", 1)
+        assert cd.prove(torch.from_numpy(w2.view(np.int64)).cuda()).to_bytes() == want, cols
     cd.close()
 
 

@@ -1480,11 +1480,19 @@ int p2gpu_prove_dev(p2gpu_circuit *c, const uint64_t *wires_dev, const uint64_t 
   return prove_impl(c, wires_dev, pis, n_pi, proof_out, proof_len, tm, 0.0);
 } P2GPU_CATCH
 
-int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
-                size_t *proof_len, p2gpu_timings *tm) try {
-  if (!c || !wires || !proof_out || !proof_len) return P2GPU_E_ARG;
-  if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
+// p2gpu_prove (ncols = W) and p2gpu_prove_sparse (ncols < W: the columns >= ncols are zero except in `row`, where
+// column j holds tail[j - ncols]; they are written in HBM instead of crossing PCIe)
+static int prove_host(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, const uint64_t *tail, uint32_t row,
+                      const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out, size_t *proof_len, p2gpu_timings *tm) {
   HIP_TRY(hipSetDevice(c->device));
+  if (ncols < c->W) {
+    // the unused wires of the witness: zeros + one value per column, made on the device (stream-ordered before
+    // every consumer below; the host part of the matrix arrives on the copy stream into the columns before them)
+    const uint32_t nt = c->W - ncols;
+    gl_t *tv = c->wires_vals.p + (size_t)ncols * c->n;
+    HIP_TRY(hipMemsetAsync(tv, 0, 8 * (size_t)nt * c->n, c->stream));
+    HIP_TRY(hipMemcpy2DAsync(tv + row, 8 * c->n, tail, 8, 8, nt, hipMemcpyHostToDevice, c->stream));
+  }
   // The witness crosses PCIe in column chunks on a copy stream; the inverse transform and the
   // LDE of a chunk run while the next chunk is still in flight (values -> coefficients -> LDE are
   // per-column; only the leaf hash needs every column).
@@ -1494,6 +1502,12 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
   const double t0 = now_ms();
   const uint32_t W = c->W, chunk = 34;  // two rate blocks
   const size_t n = c->n;
+  if (c->shard_world > 1 && ncols < c->W) {
+    // sharded proof from the compact witness: every rank uploads the dense columns itself (they are what is left
+    // of the matrix once the unused wires are made on the device); no exchange
+    HIP_TRY(hipMemcpyAsync(c->wires_vals.p, wires, 8 * (size_t)ncols * n, hipMemcpyHostToDevice, c->stream));
+    return prove_impl(c, c->wires_vals.p, pis, n_pi, proof_out, proof_len, tm, now_ms() - t0);
+  }
   if (c->shard_world > 1) {
     // Sharded proof, witness in host memory: a rank pulls only ITS block of columns
     // [q * cpr, (q + 1) * cpr) across its own PCIe link -- W / G columns, 31 MB instead of 245 MB at d = 17 and
@@ -1523,17 +1537,22 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
   }
   const uint32_t full_blocks = W / 17;
   uint32_t ci = 0;
-  for (uint32_t col0 = 0; col0 < W; col0 += chunk, ci++) {
-    const uint32_t nc = std::min(chunk, W - col0);
+  for (uint32_t col0 = 0, nc = 0; col0 < W; col0 += nc, ci++) {
+    // the chunk that holds the last column coming from the host also takes every column behind it (they are already
+    // in HBM: nothing to wait for, and each extra absorb launch is a round trip of the 200 B sponge state per row)
+    nc = col0 + chunk >= ncols ? W - col0 : chunk;
     if (ci >= c->copy_events.size()) {
       hipEvent_t e;
       HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       c->copy_events.push_back(e);
     }
     gl_t *vals = c->wires_vals.p + (size_t)col0 * n;
-    HIP_TRY(hipMemcpyAsync(vals, wires + (size_t)col0 * n, 8 * (size_t)nc * n, hipMemcpyHostToDevice, c->copy_stream));
-    HIP_TRY(hipEventRecord(c->copy_events[ci], c->copy_stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->copy_events[ci], 0));
+    const uint32_t nh = col0 < ncols ? std::min(nc, ncols - col0) : 0;  // columns of this chunk that come from the host
+    if (nh) {
+      HIP_TRY(hipMemcpyAsync(vals, wires + (size_t)col0 * n, 8 * (size_t)nh * n, hipMemcpyHostToDevice, c->copy_stream));
+      HIP_TRY(hipEventRecord(c->copy_events[ci], c->copy_stream));
+      HIP_TRY(hipStreamWaitEvent(c->stream, c->copy_events[ci], 0));
+    }
     const uint32_t *nz = batch_colnz(c, b) ? c->wire_nz.p + col0 : nullptr;
     uint32_t *cl = nz ? c->wire_clean.p + col0 : nullptr;
     if (nz) {
@@ -1547,7 +1566,7 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
               false, b.cm, W, nz ? &hl : nullptr);
     if (nz) column_clean_update(c->stream, nz, nc, cl, true);
     if (incremental) {
-      const bool last = col0 + chunk >= W;
+      const bool last = col0 + nc >= W;
       const uint32_t blk0 = col0 / 17;
       const uint32_t nblk = last ? full_blocks - blk0 : chunk / 17;
       const VirtCols v = batch_virt(c, b);
@@ -1561,7 +1580,26 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
   c->wires_ntt_done = false;
   c->wires_hash_done = false;
   return rc;
+}
+
+int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
+                size_t *proof_len, p2gpu_timings *tm) try {
+  if (!c || !wires || !proof_out || !proof_len) return P2GPU_E_ARG;
+  if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
+  return prove_host(c, wires, c->W, nullptr, 0, pis, n_pi, proof_out, proof_len, tm);
 } P2GPU_CATCH
+
+int p2gpu_prove_sparse(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, const uint64_t *tail, uint32_t row,
+                       const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out, size_t *proof_len, p2gpu_timings *tm) try {
+  if (!c || !proof_out || !proof_len || (ncols && !wires)) return P2GPU_E_ARG;
+  if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
+  if (ncols > c->W || (ncols < c->W && !tail) || row >= c->n) {
+    set_err("p2gpu_prove_sparse: %u dense columns of %u wires, row %u of %zu%s", ncols, c->W, row, c->n, (ncols < c->W && !tail) ? ", no tail values" : "");
+    return P2GPU_E_ARG;
+  }
+  return prove_host(c, wires, ncols, tail, row, pis, n_pi, proof_out, proof_len, tm);
+} P2GPU_CATCH
+
 
 // ---- stage-level operators (host buffers) ----
 int p2gpu_ifft_batch(const uint64_t *vals, size_t ncols, unsigned d, uint64_t *coeffs_out) try {

@@ -89,6 +89,8 @@ def load_library():
     lib.p2gpu_prove.argtypes = [vp, vp, vp, ctypes.c_uint32, u8p, ctypes.POINTER(sz), ctypes.POINTER(_Timings)]
     lib.p2gpu_prove_dev.argtypes = lib.p2gpu_prove.argtypes
     lib.p2gpu_prove_routed.argtypes = lib.p2gpu_prove.argtypes
+    a = lib.p2gpu_prove.argtypes
+    lib.p2gpu_prove_sparse.argtypes = [a[0], a[1], ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32] + list(a[2:])
     lib.p2gpu_fill_witness.argtypes = [vp, vp]
     lib.p2gpu_verify.argtypes = [vp, u8p, sz]
     lib.p2gpu_circuit_export_vk.argtypes = [vp, u8p, ctypes.POINTER(sz)]
@@ -313,6 +315,35 @@ class CircuitData:
         tm = _Timings()
         _check(self._lib.p2gpu_prove_routed(self._h, r.ctypes.data, pis.ctypes.data, len(pis), out.ctypes.data,
                                             ctypes.byref(plen), ctypes.byref(tm)))
+        return ProofWithPublicInputs(out[:plen.value].tobytes(), {f: getattr(tm, f) for f, _ in _Timings._fields_})
+
+    def prove_sparse(self, wires, ncols, row, public_inputs=(), tail=None):
+        """Prove from the first `ncols` wire columns plus ONE value for each of the others (``p2gpu_prove_sparse``):
+        column j >= ncols is zero in every row but `row`, where it holds ``tail[j - ncols]`` -- what plonky2 leaves
+        in the wires no gate of a circuit uses.  `wires` is the full [num_wires][degree] matrix (the tail is then
+        read off row `row`) or just its first `ncols` columns with `tail` given.  Same bytes as ``prove``; only
+        `ncols` columns cross PCIe."""
+        pis = _u64(np.array(list(public_inputs), dtype=np.uint64))
+        W, n = self.num_wires, self.degree
+        w = _u64(wires)
+        if not (0 <= ncols <= W and 0 <= row < n):
+            raise P2GpuError(-7, f"prove_sparse: ncols {ncols} of {W} wires, row {row} of {n}")
+        if tail is None:
+            if w.size != W * n:
+                raise P2GpuError(-7, f"wires must be [num_wires={W}][degree={n}] when no tail is given")
+            full = w.reshape(W, n)
+            tail = np.ascontiguousarray(full[ncols:, row])
+            w = np.ascontiguousarray(full[:ncols]).reshape(-1)
+        else:
+            tail = _u64(np.asarray(tail, dtype=np.uint64))
+        if ncols > W or w.size != ncols * n or tail.size != W - ncols:
+            raise P2GpuError(-7, f"prove_sparse: [{ncols}][{n}] dense columns and {W - ncols} tail values expected")
+        out = np.zeros(self._bound, dtype=np.uint8)
+        plen = ctypes.c_size_t(out.nbytes)
+        tm = _Timings()
+        _check(self._lib.p2gpu_prove_sparse(self._h, w.ctypes.data if w.size else None, ncols,
+                                            tail.ctypes.data if tail.size else None, row,
+                                            pis.ctypes.data, len(pis), out.ctypes.data, ctypes.byref(plen), ctypes.byref(tm)))
         return ProofWithPublicInputs(out[:plen.value].tobytes(), {f: getattr(tm, f) for f, _ in _Timings._fields_})
 
     def verify(self, proof):

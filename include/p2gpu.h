@@ -13,6 +13,7 @@
  *                             plonky2-backend/src/actions/prove_action.rs:91-97,
  *                             after witness generation (input = full wire matrix)
  *   p2gpu_prove_dev        <- same, wire matrix already resident in HBM
+ *   p2gpu_prove_sparse     <- same as p2gpu_prove for a witness whose unused wires are given as one value each
  *   p2gpu_fill_witness / p2gpu_prove_routed
  *                          <- the row-local tail of `generate_partial_witness`: the gates' own
  *                             SimpleGenerators (e.g. arithmetic_u32.rs:376-426)
@@ -132,6 +133,17 @@ int p2gpu_fill_witness(p2gpu_circuit *c, uint64_t *wires_dev);
  * all gate-internal, so they are filled on the GPU instead of crossing PCIe (80 of 234 columns). */
 int p2gpu_prove_routed(p2gpu_circuit *c, const uint64_t *routed, const uint64_t *public_inputs, uint32_t n_pi,
                        uint8_t *proof_out, size_t *proof_len, p2gpu_timings *opt_timings);
+/* prove from the first `ncols` wire columns (host, [ncols][n]) plus ONE value for each of the others: column
+ * j >= ncols is zero in every row but `row`, where it holds tail[j - ncols].  That is what plonky2 leaves in the
+ * wires no gate of a circuit uses (circuit_builder.rs randomize_unused_pi_wires: one random value in the
+ * PublicInputGate row; 154 of the 234 wires of wide_ecc_config in circuits without ECC gates,
+ * circuit_translation/mod.rs:69), so a caller that knows its circuit ships 84 MB instead of 245 MB at 2^17
+ * gates.  The columns are written in HBM and the proof is byte-identical to p2gpu_prove on the full matrix --
+ * any ncols <= num_wires and any row work (the library classifies the columns it is given, it does not trust
+ * the split); tail may be NULL when ncols == num_wires. */
+int p2gpu_prove_sparse(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, const uint64_t *tail, uint32_t row,
+                       const uint64_t *public_inputs, uint32_t n_pi, uint8_t *proof_out, size_t *proof_len,
+                       p2gpu_timings *opt_timings);
 
 /* ---- N2: prover-side precompute of `builder.build::<C>()` (host code; circuit_translation/mod.rs:80-82) ----
  * From the gate instances and the copy constraints: selector columns + groups (gates/selectors.rs), the

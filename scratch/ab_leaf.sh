@@ -7,5 +7,7 @@ for v in "$@"; do
   python bench.py --steps 32 --warmup 6 --no-cpu-baseline --pipelined 0 --profile-steps 3 $P2GPU_BENCH_FLAGS 2>/dev/null | python -c "
 import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); k=d['kernel_ms_per_proof']
 print(round(d['value'],1), 'proofs/s;', round(d['latency_ms_single_proof'],3), 'ms lone; host', d['host_witness'] and round(d['host_witness']['ms_per_proof'],2), d['host_witness'] and round(d['host_witness']['proofs_per_sec_in_flight'],1))
+sp=(d['host_witness'] or {}).get('sparse')
+if sp: print('sparse entry:', round(sp['ms_per_proof'],2), 'ms lone,', sp['proofs_per_sec_in_flight'] and round(sp['proofs_per_sec_in_flight'],1), 'proofs/s in flight,', sp['dense_columns'], 'columns over PCIe')
 print({n: v for n, v in k.items() if 'hash_lde' in n or 'fill' in n or 'ntt_pass_kernel<1, false, 12>' in n or 'quotient_kernel' in n})"
 done

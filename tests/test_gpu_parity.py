@@ -187,6 +187,37 @@ def test_structured_wire_columns_do_not_change_the_proof(pkg, orc, gpu, d, mix, 
     cd.close()
 
 
+@pytest.mark.parametrize("d,mix,ncols", [(10, "sha", 80), (10, "sha", 97), (13, "arith", 80), (9, "sha", 234), (11, "ecdsa", 231),
+                                         (8, "sha", 0), (12, "sha", 17)])
+def test_prove_sparse_matches_the_full_matrix(pkg, orc, gpu, d, mix, ncols):
+    """p2gpu_prove_sparse: the first `ncols` columns from the host, the others as ONE value each (their value in
+    the PublicInputGate row, all plonky2 leaves in the wires no gate uses) and written in HBM.  Same bytes as the
+    oracle and as p2gpu_prove on the matrix the compact form stands for -- also when the split is not the
+    circuit's (ragged ncols, no tail at all, a tail that cuts into used wires: the library classifies what it is
+    given)."""
+    blob, wires = pkg.make_circuit(d, mix, 5)
+    w = wires.reshape(234, -1)
+    nz = np.nonzero(w[233])[0]
+    row = int(nz[0]) if nz.size == 1 else 3
+    full = w.copy()
+    tail = full[ncols:, row].copy()
+    full[ncols:, :] = 0
+    full[ncols:, row] = tail
+    cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
+    if not np.array_equal(full, w):
+        cd.set("self_check", 0)        # cutting into used wires leaves an unsatisfied witness: bytes still comparable
+    else:
+        assert ncols >= 80
+    expect, _ = oc.prove(np.ascontiguousarray(full))
+    assert cd.prove_sparse(w, ncols, row).to_bytes() == expect
+    assert cd.prove_sparse(np.ascontiguousarray(full[:ncols]), ncols, row, tail=tail).to_bytes() == expect
+    assert cd.prove(np.ascontiguousarray(full)).to_bytes() == expect
+    for bad in (lambda: cd.prove_sparse(w, 235, row), lambda: cd.prove_sparse(w, ncols, w.shape[1])):
+        with pytest.raises(pkg.P2GpuError):
+            bad()
+    cd.close()
+
+
 @pytest.mark.parametrize("d,mix,npi", [(6, "arith", 1), (8, "sha", 4), (9, "ecdsa", 9), (12, "ecdsa", 20)])
 def test_public_inputs_proof_bytes_match_oracle(pkg, orc, gpu, d, mix, npi):
     """PoseidonGate rows + Poseidon public_inputs_hash (InnerHasher) on the GPU path."""

@@ -1073,7 +1073,8 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     // balance by an estimate of modmuls per row, group 0 starts with the permutation argument
     // (a PoseidonGate is not part of this: it has its own kernel, plonk.hip poseidon_gate_kernel)
     auto cost = [](const GateDesc &g) { return g.kind == G_POSEIDON ? 0u : 4u * g.num_constraints + 8u; };
-    const uint32_t perm_cost = 8u * c->R + 100u;
+    const char *pce = getenv("P2GPU_PERM_COST");  // balance experiments only
+    const uint32_t perm_cost = pce ? (uint32_t)atoi(pce) : 8u * c->R + 100u;
     uint32_t total = 0;
     for (auto &g : c->gates) total += cost(g);
     const char *env = getenv("P2GPU_GATE_GROUPS");

@@ -40,11 +40,12 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md; 6.29 TB/s is what a float4 copy reaches)
-# VALU issue ceiling measured on this chip (profiles/r02_ubench.txt, scratch/ubench/issue.hip): v_fma_f32,
-# v_xor_b32, v_bitop3_b32, v_add_co/v_addc_co, v_cmp+v_cndmask all saturate at 38-46 T lane-instr/s with 4-8
-# waves per SIMD (v_mad_u64_u32: 26-31 T); 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T is used as
-# the round number for "what one instruction per lane costs".
-VALU_PEAK = 256 * 4 * 16 * 2.4e9
+# VALU issue ceiling measured on this chip (profiles/r02_ubench.txt, scratch/ubench/issue.hip): no instruction
+# retires faster than 45.8 T lane-instr/s (v_fma_f32 and v_bitop3_b32 with 4 waves per SIMD: 45-46 T; v_xor_b32 /
+# v_add_u32 37-40 T; v_alignbit_b32, v_add_co + v_addc_co, v_cmp + v_cndmask 31-36 T; v_mad_u64_u32 26-31 T).
+# `roofline.issue.peak` is that best case, so every mix's fraction stays below 1; the ceiling of a given mix is
+# the time-weighted mean of its instructions' rates (Keccak-f, 120 bitop3 + 58 alignbit per round: ~40 T).
+VALU_PEAK = 45.8e12
 
 
 def survey_bytes(d, W, CS, K=2, PP=9, QF=8):

@@ -214,9 +214,11 @@ struct CircuitState {
   DBuf<uint64_t> hash_state;          // [cosets][25][n] sponge states between column chunks (allocated on first use)
   DBuf<uint32_t> wire_nz;             // [W] per proof, class of the wire column: 0 zero in every row, 1 zero except in
                                       // sparse_row, 2 dense (ColHints, internal.hpp); 0 and 1 are not transformed
-  DBuf<gl_t> wire_scalar;             // [W] per proof: value of a class 1 column in sparse_row
+  DBuf<gl_t> wire_scalar;             // [MAX_SPARSE_ROWS][W] per proof: value of every column in special row s ([0][.]: sparse_row)
   uint32_t sparse_row = UINT32_MAX;   // the PublicInputGate row: build() randomises its unused wires (UINT32_MAX: none)
-  DBuf<gl_t> sparse_coeffs, sparse_lde;  // inverse transform [n] and LDE [C][n] of the unit column of sparse_row
+  SparseRows sparse_rows;             // sparse_row, then the PoseidonGate rows (the public-input hash: wires 80..134 of a
+                                      // circuit without ECC gates are non-zero only there and in sparse_row): class 3 columns
+  DBuf<gl_t> sparse_coeffs, sparse_lde;  // inverse transform [rows][n] and LDE [rows][C][n] of the special rows' unit columns
   DBuf<gl_t> sparse_partial;          // per proof: [16][2] partial sums of the unit column's opening at zeta, then [2]:
                                       // the class 1 columns' joint coefficient in the FRI batch reduction
   DBuf<uint32_t> wire_nzlist;         // [1 + W]: count, then the indices of the non-zero wire columns

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void eval_columns_kernel(const gl_t *__restric
   __shared__ gl_t s0[256], s1[256];
   const uint32_t n = 1u << d;
   const uint32_t part = blockIdx.x, col = blockIdx.y;
-  if (colnz != nullptr && colnz[col] != 2) {
+  if (colnz != nullptr && colnz[col] < 2) {  // (class 3 columns have their coefficients in memory: the plain dot product)
     // class 0: the zero polynomial opens to zero; class 1: v times the unit column's polynomial, whose partial
     // sums an earlier launch left in basis_partial [parts][2]
     if (threadIdx.x == 0) {
@@ -190,7 +190,7 @@ __global__ void compact_nonzero_kernel(const uint32_t *flags, uint32_t cols, uin
   if (blockIdx.x || threadIdx.x) return;
   uint32_t k = 0;
   for (uint32_t j = 0; j < cols; j++)
-    if (flags[j] == 2) list[1 + k++] = j;
+    if (flags[j] >= 2) list[1 + k++] = j;  // dense, or class 3 (coefficients in memory, no shortcut)
   list[0] = k;
 }
 void compact_nonzero(hipStream_t st, const uint32_t *flags, uint32_t cols, uint32_t *list) {

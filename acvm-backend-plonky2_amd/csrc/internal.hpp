@@ -50,12 +50,22 @@ void ntt_plan_destroy(NttPlan *p);
 // scale (DIT only): [cosets][n] multiplied into the input; post: multiplied into the output.
 // Structured columns of a batch (the unused wires of a witness): a transform is linear, so the zero column maps to
 // zeros and v * (unit column of a fixed row) maps to v * (the transform of that unit column, kept by the handle).
+constexpr uint32_t MAX_SPARSE_ROWS = 4;  // the PublicInputGate row + up to three PoseidonGate rows
+struct SparseRows {
+  uint32_t row[MAX_SPARSE_ROWS] = {UINT32_MAX, UINT32_MAX, UINT32_MAX, UINT32_MAX};
+  uint32_t count = 0;
+};
 struct ColHints {
-  const uint32_t *cls = nullptr;    // [cols]: 0 zero, 1 = val[c] * unit column of the fixed row, 2 dense
+  const uint32_t *cls = nullptr;    // [cols]: 0 zero, 1 = val[c] * unit column of the fixed row, 2 dense,
+                                    // 3 = zero outside the handle's special rows: sum_s val[s][c] * unit column of row s
+                                    // (written by the fill kernel like class 1, but everybody else treats it as dense)
   const uint32_t *clean = nullptr;  // [cols], optional: 1 = dst already holds the zeros of class 0 column c
-  const gl_t *val = nullptr;        // [cols]: scalar of the class 1 columns
-  const gl_t *basis = nullptr;      // this transform of the unit column: [n], or [all cosets][n] (indexed by GLOBAL coset)
+  const gl_t *val = nullptr;        // [cols]: scalar of the class 1 columns; class 3: val[s * val_stride + c] for special row s
+  const gl_t *basis = nullptr;      // this transform of the unit column: [n], or [all cosets][n] (indexed by GLOBAL coset);
+                                    // special row s at basis + s * basis_stride
   bool basis_per_coset = false;
+  uint32_t nrows = 1, val_stride = 0;
+  size_t basis_stride = 0;
   uint32_t virt_first = UINT32_MAX; // columns >= virt_first (relative to cls) of class 0 / 1 are not stored at all: their
                                     // consumers recompute val[c] * basis on the fly (VirtCols)
 };
@@ -65,9 +75,10 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
 // clean[c] = 1: dst already holds the zeros of zero column c.  `after` = false, enqueued before the transforms:
 // non-zero columns lose the mark; `after` = true, enqueued behind them: zero columns gain it.
 void column_clean_update(hipStream_t st, const uint32_t *cls, uint32_t cols, uint32_t *clean, bool after);
-// class of every column of vals [cols][n] (see ColHints) with respect to `sparse_row` (UINT32_MAX: none)
-void column_flags(hipStream_t st, const gl_t *vals, uint32_t cols, uint32_t d, uint32_t sparse_row, uint32_t *flags,
-                  gl_t *scalar);
+// class of every column of vals [cols][n] (see ColHints) with respect to the special rows; scalar[s * sstride + c] =
+// the column's value in special row s
+void column_flags(hipStream_t st, const gl_t *vals, uint32_t cols, uint32_t d, const SparseRows &rows, uint32_t *flags,
+                  gl_t *scalar, uint32_t sstride);
 void fill_powers(hipStream_t st, gl_t *out, gl_t root, uint32_t count);
 void fill_coset_scale(hipStream_t st, gl_t *out, gl_t shift, gl_t wN, uint32_t d, uint32_t cosets, gl_t mult);
 void bitrev_cols(hipStream_t st, const gl_t *in, gl_t *out, uint32_t d, uint32_t cols);

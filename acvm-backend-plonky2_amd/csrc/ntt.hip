@@ -554,11 +554,29 @@ __global__ __launch_bounds__(256) void structured_fill_kernel(gl_t *dst, uint32_
   const uint32_t col = blockIdx.y;
   const uint32_t cls = h.cls[col];
   if (cls == 2u) return;
-  if (col >= h.virt_first) return;  // never read from memory: the leaf hash and the query gather recompute it
+  if (cls < 2u && col >= h.virt_first) return;  // never read from memory: the leaf hash and the query gather recompute it
   if (cls == 0u && h.clean != nullptr && h.clean[col] != 0u) return;
   const size_t n = (size_t)1 << d;
-  const gl_t v = cls == 1u ? h.val[col] : 0;
   const size_t step = (size_t)gridDim.x * blockDim.x;
+  if (cls == 3u) {  // zero outside the special rows: the same linear combination of their unit columns' transforms
+    gl_t v[MAX_SPARSE_ROWS];
+#pragma unroll
+    for (uint32_t s = 0; s < MAX_SPARSE_ROWS; s++) v[s] = s < h.nrows ? h.val[(size_t)s * h.val_stride + col] : (gl_t)0;
+    for (uint32_t coset = 0; coset < cosets; coset++) {
+      gl_t *out = dst + ((size_t)coset * col_stride + col) * n;
+      const gl_t *bs = h.basis + (h.basis_per_coset ? (size_t)(coset_first + coset * coset_stride) * n : 0);
+      for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        Acc160 acc;
+        acc.clear();
+#pragma unroll
+        for (uint32_t s = 0; s < MAX_SPARSE_ROWS; s++)
+          if (s < h.nrows) acc.mac(v[s], bs[(size_t)s * h.basis_stride + i]);
+        out[i] = acc.value();
+      }
+    }
+    return;
+  }
+  const gl_t v = cls == 1u ? h.val[col] : 0;
   for (uint32_t coset = 0; coset < cosets; coset++) {  // one block covers its slice of every coset: 8x fewer blocks to retire
     gl_t *out = dst + ((size_t)coset * col_stride + col) * n;
     const gl_t *bs = h.basis + (h.basis_per_coset ? (size_t)(coset_first + coset * coset_stride) * n : 0);
@@ -635,27 +653,29 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
 // on every unused wire of the PublicInputGate row (circuit_builder.rs randomize_unused_pi_wires; visible in the
 // reference's own proofs, tests/golden/reference_proofs.py), so in a real witness the wires no gate uses are
 // class 1 with that row, not class 0.  sparse_row = UINT32_MAX: no such row.
-__global__ __launch_bounds__(256) void column_nonzero_kernel(const gl_t *__restrict__ vals, uint32_t d, uint32_t sparse_row,
-                                                             uint32_t *flags, gl_t *scalar) {
+__global__ __launch_bounds__(256) void column_nonzero_kernel(const gl_t *__restrict__ vals, uint32_t d, SparseRows rows,
+                                                             uint32_t *flags, gl_t *scalar, uint32_t sstride) {
   const size_t n = (size_t)1 << d;
   const gl_t *p = vals + (size_t)blockIdx.y * n;
   uint64_t acc = 0;
   const size_t step = (size_t)gridDim.x * blockDim.x;
+  const uint32_t r0 = rows.row[0], r1 = rows.row[1], r2 = rows.row[2], r3 = rows.row[3];  // UINT32_MAX: never matches
 #pragma unroll 8
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
     const gl_t v = p[i];
-    acc |= (i == sparse_row) ? (gl_t)0 : v;  // a select, not a branch: the loads stay batched
+    acc |= (i == r0 || i == r1 || i == r2 || i == r3) ? (gl_t)0 : v;  // a select, not a branch: the loads stay batched
   }
-  // dense: a plain store (every wave of a dense column would otherwise hammer one address with atomics); it
-  // and the atomicMax below commute: 2 wins either way
+  // dense: a plain store (every wave of a dense column would otherwise hammer one address with atomics); the other
+  // classes are told apart from the special rows' values by column_class_kernel, launched behind this one
   if (__any(acc != 0) && (threadIdx.x & 63) == 0) flags[blockIdx.y] = 2u;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && sparse_row < n) {
-    const gl_t v = p[sparse_row];
-    if (v != 0) {
-      scalar[blockIdx.y] = v;
-      atomicMax(&flags[blockIdx.y], 1u);
-    }
-  }
+  if (blockIdx.x == 0 && threadIdx.x < rows.count) scalar[(size_t)threadIdx.x * sstride + blockIdx.y] = p[rows.row[threadIdx.x]];
+}
+__global__ void column_class_kernel(uint32_t *flags, const gl_t *scalar, uint32_t sstride, uint32_t nrows, uint32_t cols) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols || flags[c] == 2u) return;
+  bool more = false;
+  for (uint32_t s = 1; s < nrows; s++) more |= scalar[(size_t)s * sstride + c] != 0;
+  flags[c] = more ? 3u : ((nrows && scalar[c] != 0) ? 1u : 0u);
 }
 // "clean" bookkeeping of the buffers a column's transforms are written to (coefficients + LDE), so that the zeros of
 // an unused wire are stored once per handle instead of once per proof.  Both steps are stream-ordered around the
@@ -674,14 +694,15 @@ void column_clean_update(hipStream_t st, const uint32_t *nz, uint32_t cols, uint
   if (!cols) return;
   hipLaunchKernelGGL(column_clean_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, nz, cols, clean, after ? 1 : 0);
 }
-void column_flags(hipStream_t st, const gl_t *vals, uint32_t cols, uint32_t d, uint32_t sparse_row, uint32_t *flags,
-                  gl_t *scalar) {
+void column_flags(hipStream_t st, const gl_t *vals, uint32_t cols, uint32_t d, const SparseRows &rows, uint32_t *flags,
+                  gl_t *scalar, uint32_t sstride) {
   if (!cols) return;
   (void)hipMemsetAsync(flags, 0, sizeof(uint32_t) * cols, st);
   const size_t n = (size_t)1 << d;
   const uint32_t bx = (uint32_t)std::max<size_t>(1, n / (256 * 8));
   ProfScope ps("column_nonzero_kernel", 8.0 * cols * (double)n);
-  hipLaunchKernelGGL(column_nonzero_kernel, dim3(bx, cols), dim3(256), 0, st, vals, d, sparse_row, flags, scalar);
+  hipLaunchKernelGGL(column_nonzero_kernel, dim3(bx, cols), dim3(256), 0, st, vals, d, rows, flags, scalar, sstride);
+  hipLaunchKernelGGL(column_class_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, flags, scalar, sstride, rows.count, cols);
 }
 
 // ---- tables -------------------------------------------------------------------

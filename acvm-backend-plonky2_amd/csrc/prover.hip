@@ -314,6 +314,9 @@ ColHints wire_hints(const p2gpu_circuit *c, uint32_t col0, bool lde) {
   h.val = c->wire_scalar.p + col0;
   h.basis = lde ? c->sparse_lde.p : c->sparse_coeffs.p;
   h.basis_per_coset = lde;
+  h.nrows = c->sparse_rows.count;
+  h.val_stride = c->W;
+  h.basis_stride = lde ? (size_t)c->C * c->n : c->n;
   const uint32_t vf = virt_first(c);
   if (lde && vf != UINT32_MAX) h.virt_first = vf > col0 ? vf - col0 : 0;
   return h;
@@ -359,7 +362,7 @@ int batch_commit_from_values(p2gpu_circuit *c, Batch &b, const gl_t *vals_dev) {
     // gates): one pass over the witness finds them, and their inverse transform and LDE become stores of zeros
     const uint32_t *nz = batch_colnz(c, b);
     if (nz) {
-      column_flags(c->stream, vals_dev, b.cols, c->d, c->sparse_row, c->wire_nz.p, c->wire_scalar.p);
+      column_flags(c->stream, vals_dev, b.cols, c->d, c->sparse_rows, c->wire_nz.p, c->wire_scalar.p, c->W);
       column_clean_update(c->stream, nz, b.cols, c->wire_clean.p, false);
     }
     gl_t ninv = gl_inv((gl_t)c->n);
@@ -793,7 +796,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
       const uint32_t r = rq, k = brev((uint32_t)(x & (n - 1)), d);
       const uint32_t z = (r - b.cm.first) / b.cm.stride;
       for (uint32_t col = 0; col < b.cols; col++) {
-        if (o == 1 && col >= vfirst && h_cls[col] != 2u) {
+        if (o == 1 && col >= vfirst && h_cls[col] < 2u) {
           // unmaterialised column: class 0 opens to 0, class 1 to val * LDE(unit column)[r][k] (product taken on the host)
           const bool c1 = h_cls[col] == 1u && c->sparse_lde.p;
           if (c1) virt_fix.emplace_back(ptrs.size(), col);
@@ -1177,6 +1180,13 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
       rg[row] = (uint8_t)gi;
       if (c->sparse_row == UINT32_MAX && c->gates[gi].kind == G_PUBLIC_INPUT) c->sparse_row = (uint32_t)row;
     }
+    // the special rows of the column classification: the PublicInputGate row first, then the PoseidonGate rows
+    c->sparse_rows = SparseRows();
+    if (c->sparse_row != UINT32_MAX) {
+      c->sparse_rows.row[c->sparse_rows.count++] = c->sparse_row;
+      for (size_t row = 0; row < n && c->sparse_rows.count < MAX_SPARSE_ROWS; row++)
+        if (c->gates[rg[row]].kind == G_POSEIDON) c->sparse_rows.row[c->sparse_rows.count++] = (uint32_t)row;
+    }
     const uint32_t ngc = c->NC - c->num_selectors;
     CK(c->d_row_gate.alloc(n), "alloc row_gate");
     CK(c->d_gconsts.alloc((size_t)(ngc ? ngc : 1) * n), "alloc gconsts");
@@ -1199,19 +1209,23 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   CK(c->wire_nzlist.alloc(c->W + 1), "alloc wire flags");
   CK(c->wire_clean.alloc(c->W), "alloc wire flags");
   CK(hipMemsetAsync(c->wire_clean.p, 0, sizeof(uint32_t) * c->W, c->stream), "clear wire flags");
-  CK(c->wire_scalar.alloc(c->W), "alloc wire flags");
+  CK(c->wire_scalar.alloc((size_t)MAX_SPARSE_ROWS * c->W), "alloc wire flags");
   if (c->sparse_row != UINT32_MAX) {
     // inverse transform and LDE (all cosets) of the unit column of the PublicInputGate row: what a wire that is
-    // zero everywhere but there transforms to, up to its scalar
-    CK(c->sparse_coeffs.alloc(n), "alloc sparse basis");
-    CK(c->sparse_lde.alloc((size_t)C * n), "alloc sparse basis");
+    // zero everywhere but there transforms to, up to its scalar -- and the same for the PoseidonGate rows
+    // (sparse_rows: columns that are zero outside these rows are their linear combination, class 3)
+    const uint32_t nr = c->sparse_rows.count;
+    CK(c->sparse_coeffs.alloc((size_t)nr * n), "alloc sparse basis");
+    CK(c->sparse_lde.alloc((size_t)nr * C * n), "alloc sparse basis");
     CK(c->sparse_partial.alloc(16 * 2 + 2), "alloc sparse basis");
     const gl_t one = 1;
-    CK(hipMemsetAsync(c->sparse_coeffs.p, 0, 8 * n, st), "sparse basis");
-    CK(hipMemcpyAsync(c->sparse_coeffs.p + c->sparse_row, &one, 8, hipMemcpyHostToDevice, st), "sparse basis");
+    CK(hipMemsetAsync(c->sparse_coeffs.p, 0, 8 * (size_t)nr * n, st), "sparse basis");
+    for (uint32_t s = 0; s < nr; s++)
+      CK(hipMemcpyAsync(c->sparse_coeffs.p + (size_t)s * n + c->sparse_rows.row[s], &one, 8, hipMemcpyHostToDevice, st), "sparse basis");
     CK(hipStreamSynchronize(st), "sparse basis");  // `one` lives on this stack frame
-    ntt_batch(st, c->plan_inv, c->sparse_coeffs.p, c->sparse_coeffs.p, 1, 1, nullptr, gl_inv((gl_t)n), false);
-    ntt_batch(st, c->plan_fwd, c->sparse_coeffs.p, c->sparse_lde.p, 1, C, c->scale.p, 1, false);
+    ntt_batch(st, c->plan_inv, c->sparse_coeffs.p, c->sparse_coeffs.p, nr, 1, nullptr, gl_inv((gl_t)n), false);
+    for (uint32_t s = 0; s < nr; s++)  // [rows][C][n]: one column per launch keeps every row's cosets together
+      ntt_batch(st, c->plan_fwd, c->sparse_coeffs.p + (size_t)s * n, c->sparse_lde.p + (size_t)s * C * n, 1, C, c->scale.p, 1, false);
   }
   CK(c->zp_vals.alloc((size_t)nzp * n), "alloc zp");
   CK(c->cp.alloc((size_t)K * c->nchunks * n), "alloc cp");
@@ -1557,7 +1571,7 @@ static int prove_host(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, c
     const uint32_t *nz = batch_colnz(c, b) ? c->wire_nz.p + col0 : nullptr;
     uint32_t *cl = nz ? c->wire_clean.p + col0 : nullptr;
     if (nz) {
-      column_flags(c->stream, vals, nc, c->d, c->sparse_row, c->wire_nz.p + col0, c->wire_scalar.p + col0);
+      column_flags(c->stream, vals, nc, c->d, c->sparse_rows, c->wire_nz.p + col0, c->wire_scalar.p + col0, c->W);
       column_clean_update(c->stream, nz, nc, cl, false);
     }
     const ColHints hi = nz ? wire_hints(c, col0, false) : ColHints(), hl = nz ? wire_hints(c, col0, true) : ColHints();

@@ -187,6 +187,45 @@ def test_structured_wire_columns_do_not_change_the_proof(pkg, orc, gpu, d, mix, 
     cd.close()
 
 
+@pytest.mark.parametrize("d,mix,npi", [(10, "sha", 4), (12, "sha", 20), (11, "arith", 1), (13, "sha", 40), (9, "ecdsa", 9)])
+def test_structured_columns_with_public_inputs(pkg, orc, gpu, d, mix, npi):
+    """With public inputs the circuit has PoseidonGate rows (the public-input hash, one per 8 inputs): wires 80..134
+    are then non-zero in those rows and in the PublicInputGate row only.  Such columns are a linear combination of up
+    to four unit columns (class 3: the PublicInputGate row and the first three PoseidonGate rows) and are written by
+    the fill kernel instead of being transformed; with more Poseidon rows than that they are plain dense columns.
+    Same bytes as the oracle with the shortcuts on and off, on every entry point."""
+    import torch
+
+    blob, wires, pis = pkg.make_circuit(d, mix, 31, num_public_inputs=npi)
+    w = wires.reshape(234, -1)
+    per_col = (w != 0).sum(axis=1)
+    if mix != "ecdsa":
+        assert (per_col[135:] == 1).all() and (per_col[80:135] >= 2).all() and (per_col[80:135] <= 1 + (npi + 7) // 8).all()
+    cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
+    expect, _ = oc.prove(wires, public_inputs=pis)
+    wd = torch.from_numpy(wires.view(np.int64)).cuda()
+    pi_row = int(np.nonzero(w[233])[0][0]) if mix != "ecdsa" else 0
+    for knob, virt in ((1, 1), (0, 1), (1, 0), (1, 1)):
+        cd.set("zero_columns", knob)
+        cd.set("virtual_columns", virt)
+        assert cd.prove(wd, public_inputs=pis).to_bytes() == expect
+        assert cd.prove(wires, public_inputs=pis).to_bytes() == expect
+        if mix != "ecdsa":
+            assert cd.prove_sparse(wires, 135, pi_row, public_inputs=pis).to_bytes() == expect
+    # a Poseidon-row value turning up in a column that was class 1, and a class 3 column losing its second row
+    cd.set("self_check", 0)
+    if mix != "ecdsa":
+        rows3 = np.nonzero(w[100])[0]
+        w2 = wires.copy().reshape(234, -1)
+        w2[200, rows3[-1]] = 7
+        w2[90, rows3[rows3 != pi_row][0]] = 0
+        w2 = np.ascontiguousarray(w2)
+        want, _ = oc.prove(w2, public_inputs=pis)
+        assert cd.prove(torch.from_numpy(w2.view(np.int64)).cuda(), public_inputs=pis).to_bytes() == want
+        assert cd.prove(w2, public_inputs=pis).to_bytes() == want
+    cd.close()
+
+
 @pytest.mark.parametrize("d,mix,ncols", [(10, "sha", 80), (10, "sha", 97), (13, "arith", 80), (9, "sha", 234), (11, "ecdsa", 231),
                                          (8, "sha", 0), (12, "sha", 17)])
 def test_prove_sparse_matches_the_full_matrix(pkg, orc, gpu, d, mix, ncols):

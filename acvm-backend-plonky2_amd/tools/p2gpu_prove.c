@@ -7,7 +7,8 @@
  * The counterpart of `plonky2-backend prove -b <acir> -w <witness> -o <proof>`
  * (plonky2-backend/src/argument_parsing.rs:36-41 -> actions/prove_action.rs:27-43) below the
  * translation layer: the circuit blob is what the Rust side exports once per circuit and
- * wires.bin is the dense witness matrix [num_wires][n] of little-endian u64 (with --routed only
+ * wires.bin is the dense witness matrix [num_wires][n] of little-endian u64 (with --sparse <ncols> <row>: its
+ * first ncols columns followed by the value each other column holds in <row>, p2gpu_prove_sparse; with --routed only
  * the [num_routed_wires][n] routed columns; the rest is derived on the GPU).  Writes the
  * uncompressed ProofWithPublicInputs bytes; --vk also writes the verifier's share of the circuit for
  * p2gpu-verify (the reference's `write_vk`, actions/write_vk_action.rs:65-81); --reference-format
@@ -36,16 +37,22 @@ static void *slurp(const char *path, size_t *len) {
 }
 
 int main(int argc, char **argv) {
-  int routed = 0, npos = 0, ref_format = 0;
+  int routed = 0, npos = 0, ref_format = 0, sparse = 0;
+  unsigned long sp_cols = 0, sp_row = 0;
   const char *pos[4] = {0, 0, 0, 0}, *vk_path = NULL;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--routed")) routed = 1;
     else if (!strcmp(argv[i], "--reference-format")) ref_format = 1;
+    else if (!strcmp(argv[i], "--sparse") && i + 2 < argc) {
+      sparse = 1;
+      sp_cols = strtoul(argv[++i], NULL, 10);
+      sp_row = strtoul(argv[++i], NULL, 10);
+    }
     else if (!strcmp(argv[i], "--vk") && i + 1 < argc) vk_path = argv[++i];
     else if (npos < 4) pos[npos++] = argv[i];
   }
   if (npos < 3) {
-    fprintf(stderr, "usage: %s <circuit.blob> <wires.bin> <proof.bin> [public_inputs.bin] [--routed] [--vk <vk.blob>] [--reference-format]\n", argv[0]);
+    fprintf(stderr, "usage: %s <circuit.blob> <wires.bin> <proof.bin> [public_inputs.bin] [--routed] [--sparse <ncols> <row>] [--vk <vk.blob>] [--reference-format]\n", argv[0]);
     return 1;
   }
   size_t blob_len, wires_len, pi_len = 0;
@@ -64,7 +71,13 @@ int main(int argc, char **argv) {
     uint32_t h[64];
     memcpy(h, blob, sizeof h);
     const uint64_t cols = routed ? h[4] : h[3];
-    if (h[2] < 40 && wires_len != 8ull * cols * (1ull << h[2])) {
+    if (sparse) { /* [ncols][2^d] dense columns, then one value for each of the num_wires - ncols others */
+      if (sp_cols > h[3] || h[2] >= 40 || wires_len != 8ull * (sp_cols * (1ull << h[2]) + (h[3] - sp_cols))) {
+        fprintf(stderr, "%s: %zu bytes, --sparse %lu needs [%lu][2^%u] + %lu u64\n", pos[1], wires_len, sp_cols, sp_cols, h[2],
+                (unsigned long)h[3] - sp_cols);
+        return 1;
+      }
+    } else if (h[2] < 40 && wires_len != 8ull * cols * (1ull << h[2])) {
       fprintf(stderr, "%s: %zu bytes, but the circuit needs %s[%u][2^%u] u64 = %llu bytes\n", pos[1], wires_len,
               routed ? "routed" : "wires", (unsigned)cols, h[2], (unsigned long long)(8ull * cols * (1ull << h[2])));
       return 1;
@@ -97,8 +110,14 @@ int main(int argc, char **argv) {
   size_t cap = p2gpu_proof_size_bound(c), len = cap;
   uint8_t *proof = malloc(cap);
   p2gpu_timings t;
-  rc = routed ? p2gpu_prove_routed(c, wires, pis, (uint32_t)(pi_len / 8), proof, &len, &t)
-              : p2gpu_prove(c, wires, pis, (uint32_t)(pi_len / 8), proof, &len, &t);
+  if (sparse) {
+    uint32_t h[64];
+    memcpy(h, blob, sizeof h);
+    rc = p2gpu_prove_sparse(c, wires, (uint32_t)sp_cols, wires + sp_cols * (1ull << h[2]), (uint32_t)sp_row, pis, (uint32_t)(pi_len / 8),
+                            proof, &len, &t);
+  } else
+    rc = routed ? p2gpu_prove_routed(c, wires, pis, (uint32_t)(pi_len / 8), proof, &len, &t)
+                : p2gpu_prove(c, wires, pis, (uint32_t)(pi_len / 8), proof, &len, &t);
   if (rc) {
     fprintf(stderr, "p2gpu_prove: %d: %s\n", rc, p2gpu_last_error());
     p2gpu_circuit_destroy(c);

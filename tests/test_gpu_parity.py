@@ -445,7 +445,15 @@ def test_standalone_c_caller(pkg, orc, gpu, tmp_path):
     (tmp_path / "r.bin").write_bytes(np.ascontiguousarray(wires[:80]).tobytes())
     (tmp_path / "pi.bin").write_bytes(pis.tobytes())
     expect, _ = orc.OracleCircuit(blob).prove(wires, public_inputs=pis)
-    for args, out in ((["w.bin", "--vk", str(tmp_path / "vk.blob")], "p1.bin"), (["r.bin", "--routed"], "p2.bin")):
+    # --sparse: the first 231 columns + the value of each other column in row 0 (their only non-zero row here or not:
+    # the tool proves the matrix that compact form stands for, which is `wires` when the tail columns are zero elsewhere)
+    w2 = wires.reshape(234, -1)
+    tail_only_row0 = not w2[231:, 1:].any()
+    (tmp_path / "s.bin").write_bytes(np.ascontiguousarray(w2[:231]).tobytes() + np.ascontiguousarray(w2[231:, 0]).tobytes())
+    runs = [(["w.bin", "--vk", str(tmp_path / "vk.blob")], "p1.bin"), (["r.bin", "--routed"], "p2.bin")]
+    if tail_only_row0:
+        runs.append((["s.bin", "--sparse", "231", "0"], "p4.bin"))
+    for args, out in runs:
         cmd = [exe, str(tmp_path / "c.blob"), str(tmp_path / args[0]), str(tmp_path / out), str(tmp_path / "pi.bin")] + args[1:]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr

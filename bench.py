@@ -72,6 +72,7 @@ KERNEL_STEP = [
     ("ntt_pass_kernel<1,", "lde"), ("lde_", "lde"), ("ntt_pass_kernel<0,", "intt"), ("intt_", "intt"),
     ("hash_lde", "leaf_hash"), ("merkle", "merkle"), ("zs_", "zs"), ("quotient", "quotient"), ("poseidon_gate", "quotient"),
     ("eval_columns", "openings_fri_reduce"), ("reduce_columns", "openings_fri_reduce"),
+    ("structured_fill", "lde"), ("column_nonzero", "intt"),   # the structured columns' share of those steps
 ]
 
 
@@ -476,6 +477,11 @@ def main():
                                         "VALU-issue-bound, see `issue`",
                                 "frac_at_throughput": total_b * (total_proofs / world / dt) / 1e9 / HBM_PEAK_GBPS},
                 "issue": issue_roofline(name, 1e3 / avg_ms),
+                # every prover step by SURVEY 8(d)'s bytes over the summed HIP-event time of its kernels (per proof)
+                "steps": {stp: {"algorithmic_bytes": steps_b[stp], "kernel_ms": ms_, "achieved_GBps": steps_b[stp] / (ms_ * 1e-3) / 1e9,
+                                "frac": steps_b[stp] / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                          for stp in steps_b
+                          for ms_ in [sum(v["ms"] for k, v in stats.items() if step_of(k) == stp) / P] if ms_ > 0},
             },
             "latency_ms_single_proof": single_ms,
             "single_proof": {"in_flight": 1, "ms_per_proof": single_ms, "proofs_per_sec": (1 if sharded else world) * 1e3 / single_ms,

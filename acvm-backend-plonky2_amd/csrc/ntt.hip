@@ -138,7 +138,10 @@ constexpr int MAX_ROUNDS = 4;
 #ifndef NTT_PHI
 #define NTT_PHI 0  // 1: butterfly networks on signed a + b*2^32 components (glphi.hpp).  Measured on MI355X (d = 17):
                    // 21 % fewer VALU per radix-16 round, but 150-200 VGPRs instead of 98 (2-3 waves per SIMD
-                   // instead of 4): LDE 3.42 ms vs 3.22 ms -- not faster, so it stays an opt-in variant
+                   // instead of 4): LDE 3.42 ms vs 3.22 ms.  Re-measured with the radix-8 rounds (NTT_PER 8): 68-80 VGPRs,
+                   // 6-7 waves per SIMD, no scratch, bit-exact -- and still slower (LDE 1.36 vs 1.21 ms, sha mix; 2.91 vs 2.52
+                   // with 231 dense columns): its 64-bit shifts and adds retire slower than the carry chains they replace.
+                   // It stays an opt-in variant
 #endif
 #ifndef NTT_TILE_BITS
 #define NTT_TILE_BITS 12

@@ -229,6 +229,7 @@ struct CircuitState {
   int virtual_columns = 1;            // knob "virtual_columns": structured columns >= max(R, gate_wires) get no LDE in memory (VirtCols)
   // tables
   DBuf<gl_t> tw_fwd, tw_inv, scale, inv_scale, d_kis, d_sigmas, fri_scale, qconst;
+  DBuf<gl_t> l0_lde;  // [C][n]: L_0(x) = Z_H(x) / (n (x - 1)) on every LDE point (the quotient kernel's one inversion per row, tabulated)
   DBuf<GateDesc> d_gates;
   DBuf<uint8_t> d_row_gate;   // [n] gate index of every row (from the selector columns)
   DBuf<gl_t> d_gconsts, d_prc; // gate-constant columns [NC - num_selectors][n]; Poseidon round constants

@@ -305,7 +305,25 @@ P2_HD gl_t gl_pow(gl_t b, uint64_t e) {
   }
   return r;
 }
-P2_HD gl_t gl_inv(gl_t a) { return gl_pow(a, GL_P - 2); }
+// a^(p-2), p - 2 = 2^64 - 2^32 - 1 = 31 ones, a zero, 32 ones: a^(2^31 - 1) by doubling the run of ones
+// (30 squarings + 8 products), then (a^(2^31-1))^(2^33) * a^(2^32-1): 64 squarings + 10 products instead of the
+// 63 + 62 of plain square-and-multiply.  gl_inv(0) = 0.
+P2_HD gl_t gl_sqr_n(gl_t a, int k) {
+  for (int i = 0; i < k; i++) a = gl_mul(a, a);
+  return a;
+}
+P2_HD gl_t gl_inv(gl_t a) {
+  const gl_t e2 = gl_mul(gl_mul(a, a), a);            // 2 ones
+  const gl_t e4 = gl_mul(gl_sqr_n(e2, 2), e2);
+  const gl_t e8 = gl_mul(gl_sqr_n(e4, 4), e4);
+  const gl_t e16 = gl_mul(gl_sqr_n(e8, 8), e8);
+  const gl_t e24 = gl_mul(gl_sqr_n(e16, 8), e8);
+  const gl_t e28 = gl_mul(gl_sqr_n(e24, 4), e4);
+  const gl_t e30 = gl_mul(gl_sqr_n(e28, 2), e2);
+  const gl_t e31 = gl_mul(gl_mul(e30, e30), a);        // a^(2^31 - 1)
+  const gl_t e32 = gl_mul(gl_mul(e31, e31), a);        // a^(2^32 - 1)
+  return gl_mul(gl_sqr_n(e31, 33), e32);
+}
 // primitive 2^k-th root of unity
 P2_HD gl_t gl_root(unsigned k) {
   gl_t g = GL_ROOT_2_32;

@@ -148,8 +148,12 @@ struct QuotArgs {
   const gl_t *qconst;   // device [3][8]: coset shift g w_N^r | Z_H = g^n w_8^r - 1 | 1 / Z_H (g = GL_GEN)
                         // (in memory, not kernel arguments: they are indexed by blockIdx.y)
   gl_t n_inv;           // 1/n
+  const gl_t *l0;       // [all cosets][n] (global coset index): L_0(x) = Z_H(x) / (n (x - 1)), fill_l0_table
 };
 void quotient_eval(hipStream_t st, const QuotArgs &a);
+// out[r][k] = qconst[8 + r] * n_inv / (qconst[r] * w_n^k - 1): per circuit, so that the quotient kernel loads L_0
+// instead of inverting x - 1 on every row (~125 modmuls of the ~1 200 a row of the permutation argument costs)
+void fill_l0_table(hipStream_t st, const gl_t *qconst, const gl_t *tw, uint32_t tw_shift, uint32_t d, uint32_t cosets, gl_t n_inv, gl_t *out);
 // upload the Poseidon round constants used by PoseidonGate evaluation; 0 = ok
 int poseidon_upload_constants();
 // cross-coset inverse butterflies.  in [K][C][n]: per-coset inverse transforms of

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, P2_QUOT_WAVES) void quotient_kernel(const Quot
   out.t = 0;
   if (grp == 0) {
   // L_0(x) (Z_c(x) - 1),  L_0(x) = Z_H(x) / (n (x - 1))
-  const gl_t l0 = gl_mul(gl_mul(a.qconst[8 + r], a.n_inv), gl_inv(gl_sub(x, 1)));
+  const gl_t l0 = a.l0[(size_t)r * n + k];
   for (uint32_t c = 0; c < a.K; c++) out.emit(gl_mul(l0, gl_sub(zl[(size_t)c * n + k], 1)));
   // partial-product checks: prev * prod(num) - next * prod(den), chunk by chunk, both challenges
   {
@@ -305,6 +305,19 @@ __global__ __launch_bounds__(256) void poseidon_gate_kernel(const QuotArgs a, ui
     gl_t *o1 = a.out + ((size_t)1 * a.ncosets + z) * n + k;
     *o1 = gl_mul_add(fz, out.acc1.value(), *o1);
   }
+}
+
+__global__ __launch_bounds__(256) void l0_table_kernel(const gl_t *qconst, const gl_t *tw, uint32_t tw_shift, uint32_t d, gl_t n_inv,
+                                                       gl_t *out) {
+  const uint32_t n = 1u << d;
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (k >= n) return;
+  const gl_t x = gl_mul(qconst[r], root_pow(tw, tw_shift, d, k));
+  out[(size_t)r * n + k] = gl_mul(gl_mul(qconst[8 + r], n_inv), gl_inv(gl_sub(x, 1)));
+}
+void fill_l0_table(hipStream_t st, const gl_t *qconst, const gl_t *tw, uint32_t tw_shift, uint32_t d, uint32_t cosets, gl_t n_inv, gl_t *out) {
+  const uint32_t n = 1u << d, threads = n >= 256 ? 256 : 64;
+  hipLaunchKernelGGL(l0_table_kernel, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, qconst, tw, tw_shift, d, n_inv, out);
 }
 
 void quotient_eval(hipStream_t st, const QuotArgs &a) {

@@ -530,6 +530,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     q.qconst = c->qconst.p;
     (void)wN;
     q.n_inv = gl_inv((gl_t)n);
+    q.l0 = c->l0_lde.p;
     {
       quotient_eval(st, q);
     }
@@ -935,7 +936,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
 
 void circuit_release(p2gpu_circuit *c) {
   c->tw_fwd.release(); c->tw_inv.release(); c->scale.release(); c->inv_scale.release(); c->d_kis.release();
-  c->d_sigmas.release(); c->fri_scale.release(); c->d_gates.release(); c->qconst.release();
+  c->d_sigmas.release(); c->fri_scale.release(); c->d_gates.release(); c->qconst.release(); c->l0_lde.release();
   c->d_row_gate.release(); c->d_gconsts.release(); c->d_prc.release(); c->qconst.release();
   c->cs.release(); c->wires.release(); c->zp.release(); c->quot.release();
   c->wires_vals.release(); c->zp_vals.release(); c->cp.release(); c->rowprod.release(); c->scan_tmp.release();
@@ -1160,6 +1161,8 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
       qc[16 + r] = gl_inv(qc[8 + r]);
     }
     CK(hipMemcpy(c->qconst.p, qc, sizeof qc, hipMemcpyHostToDevice), "copy qconst");
+    CK(c->l0_lde.alloc((size_t)C * n), "alloc L0 table");
+    fill_l0_table(st, c->qconst.p, c->tw_fwd.p, 0, d, C, gl_inv((gl_t)n), c->l0_lde.p);
   }
   mark("root tables + ntt plans");
   CK(hipMemcpyAsync(c->d_kis.p, k_is, 8 * (size_t)c->R, hipMemcpyHostToDevice, st), "copy kis");

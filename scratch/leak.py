@@ -5,12 +5,13 @@ sys.path.insert(0, "/root/repo")
 import __graft_entry__ as entry
 import torch
 pkg = entry.load_package()
-blob, wires = pkg.make_circuit(15, "ecdsa", 1)
+blob, wires, pis = pkg.make_circuit(15, "sha", 1, num_public_inputs=9)
 free0 = None
 for it in range(25):
     cd = pkg.CircuitData(blob)
-    cd.prove(wires)
-    vd = cd.verifier_data(); vd.verify(cd.prove(wires)); vd.close()
+    cd.prove(wires, public_inputs=pis)
+    cd.prove_sparse(wires, 135, int(np.nonzero(wires.reshape(234, -1)[233])[0][0]), public_inputs=pis)
+    vd = cd.verifier_data(); vd.verify(cd.prove(wires, public_inputs=pis)); vd.close()
     cd.close()
     torch.cuda.synchronize()
     free, total = torch.cuda.mem_get_info()

@@ -575,6 +575,21 @@ def _assert_matches_gold(pkg, blob, wires, pis, g):
     assert bad is None, f"first diverging prover stage: {bad}"
     assert hashlib.sha256(proof.to_bytes()).hexdigest() == g["proof_sha256"]
     cd.verify(proof)
+    # the other entry points and the shortcuts' off switches at this size: resident witness, the compact witness
+    # when the matrix has that form (the unused wires non-zero in one common row only), everything dense
+    import torch
+
+    want = g["proof_sha256"]
+    assert hashlib.sha256(cd.prove(torch.from_numpy(wires.view(np.int64)).cuda(), public_inputs=pis).to_bytes()).hexdigest() == want
+    wm = wires.reshape(cd.num_wires, -1)
+    nzc = (wm != 0).sum(axis=1)
+    ncols = int(np.max(np.nonzero(nzc > 1)[0])) + 1 if (nzc > 1).any() else 0
+    rows = {int(np.nonzero(wm[j])[0][0]) for j in range(ncols, cd.num_wires) if nzc[j] == 1}
+    if len(rows) == 1 and ncols < cd.num_wires:
+        assert hashlib.sha256(cd.prove_sparse(wires, ncols, rows.pop(), public_inputs=pis).to_bytes()).hexdigest() == want
+    if wires.size <= 234 << 17:
+        cd.set("zero_columns", 0)
+        assert hashlib.sha256(cd.prove(wires, public_inputs=pis).to_bytes()).hexdigest() == want
     cd.close()
 
 

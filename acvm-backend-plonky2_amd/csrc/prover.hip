@@ -1518,7 +1518,14 @@ static int prove_host(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, c
   // columns that have arrived are absorbed chunk by chunk too (states wait in HBM), so that after
   // the last chunk only its own two permutations and the tree remain.
   const double t0 = now_ms();
-  const uint32_t W = c->W, chunk = 34;  // two rate blocks
+  static const uint32_t chunk_cols = [] {
+    // rate blocks (17 columns) per upload chunk; the override is for measurements (scratch/chunk_sweep.sh, 2^20 rows:
+    // 2 blocks 8.74 ms lone / 163-171 proofs/s in flight, 3: 8.70 / 174, 4: 8.56 / 160, 6: 8.88 / 154)
+    const char *e = getenv("P2GPU_CHUNK_BLOCKS");
+    const int b = e ? atoi(e) : 2;
+    return (uint32_t)(17 * (b >= 1 && b <= 64 ? b : 2));
+  }();
+  const uint32_t W = c->W, chunk = chunk_cols;  // two rate blocks
   const size_t n = c->n;
   if (c->shard_world > 1 && ncols < c->W) {
     // sharded proof from the compact witness: every rank uploads the dense columns itself (they are what is left

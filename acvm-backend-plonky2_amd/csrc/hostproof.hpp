@@ -38,6 +38,10 @@ struct Cursor {
     dig_t d;
     memset(&d, 0, sizeof d);
     if (const uint8_t *q = take(hh_bytes())) memcpy(d.w, q, hh_bytes());
+    // PoseidonHash digests are 4 field elements: w and w + p hash alike, so only the canonical encoding is a proof
+    if (g_hh.kind)
+      for (int i = 0; i < 4; i++)
+        if (d.w[i] >= GL_P) ok = false;
     return d;
   }
   void digests(std::vector<dig_t> &v, size_t n) {

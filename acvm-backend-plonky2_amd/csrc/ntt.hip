@@ -131,8 +131,16 @@ __device__ __forceinline__ void dft_regs(gl_t (&v)[1 << LOGR]) {
   });
 }
 
-// LDS index padding: one extra slot per 16 so that 16-element strides do not collide on banks
-__device__ __forceinline__ uint32_t pidx(uint32_t e) { return e + (e >> 4); }
+// LDS index swizzle (round 3; replaces the "one pad slot per 16" of rounds 1-2, which left 61 % of the kernel's LDS cycles
+// as bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS of profiles/r02i_sq_summary.json).  ds_read_b64 serves a
+// wave in two groups of 32 lanes over 32 eight-byte slots, ds_write_b64 in four groups of 16 lanes over 16 slots
+// (MI355X_MICROARCH.md, LDS).  In a round on tile bits [beta0, beta0 + 3) the lanes of a group differ in element bits
+// {3..7} (beta0 = 0), {0,1,2,6,7} (beta0 = 3) or {0..4} (beta0 >= 5, and the load / store phases): the slot bits
+//   s0 = e0^e4, s1 = e1^e5, s2 = e2^e6, s3 = e3^e6, s4 = e4^e7
+// are a GF(2)-linear map of full rank on each of those sets (and s0..s3 on the first four bits of each for the
+// stores), so every access of the d >= 12 plans is conflict-free with no padding at all.  Linear means
+// swz(a ^ b) = swz(a) ^ swz(b): a lane's eight addresses are swz(base) ^ swz(j << beta0), the second term wave-uniform.
+__device__ __forceinline__ uint32_t pidx(uint32_t e) { return e ^ ((e >> 4) & 7u) ^ ((e >> 3) & 0x18u); }
 
 constexpr int MAX_ROUNDS = 4;
 #ifndef NTT_PHI
@@ -264,12 +272,12 @@ __device__ __forceinline__ void round_regs(gl_t *lds, const PassArgs &A, uint32_
   constexpr int R = 1 << LOGR;
   const uint32_t ngroups = 1u << (TB - LOGR);
   const uint32_t s0 = beta0 - A.tb + A.s;  // log2 M
-  // Index arithmetic is a tenth of this kernel's instructions if done per access: the padded LDS index
-  // e + (e >> 4) of element base | (j << beta0) is LINEAR in j whenever the round's bits lie entirely above
-  // or entirely below bit 4 (every round of the d = 17 plans), and the packed twiddle table is walked with
-  // one 64-bit add per entry.
-  const bool linear = beta0 >= 4 || beta0 + LOGR <= 4;
-  const uint32_t lstride = beta0 >= 4 ? (1u << beta0) + (1u << (beta0 - 4)) : (1u << beta0);
+  // Index arithmetic is a tenth of this kernel's instructions if done per access: the swizzled LDS index of element
+  // base | (j << beta0) is pidx(base) ^ pidx(j << beta0) (the swizzle is GF(2)-linear), the second term wave-uniform;
+  // the packed twiddle table is walked with one 64-bit add per entry.
+  uint32_t lj[R];
+#pragma unroll
+  for (int j = 0; j < R; j++) lj[j] = pidx((uint32_t)j << beta0);
   const size_t tstride = (size_t)1 << s0;
   for (uint32_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
     const uint32_t low = g & ((1u << beta0) - 1), high = g >> beta0;
@@ -277,13 +285,10 @@ __device__ __forceinline__ void round_regs(gl_t *lds, const PassArgs &A, uint32_
     const uint32_t lo = (((base & ((1u << beta0) - 1)) >> A.tb) << A.s) + lo0 + (base & ((1u << A.tb) - 1));
     gl_t v[R];
     uint32_t li[R];
-    if (linear) {
+    {
       const uint32_t l0 = pidx(base);
 #pragma unroll
-      for (int j = 0; j < R; j++) li[j] = l0 + (uint32_t)j * lstride;
-    } else {
-#pragma unroll
-      for (int j = 0; j < R; j++) li[j] = pidx(base | ((uint32_t)j << beta0));
+      for (int j = 0; j < R; j++) li[j] = l0 ^ lj[j];
     }
 #pragma unroll
     for (int j = 0; j < R; j++) v[j] = lds[li[j]];
@@ -363,8 +368,8 @@ __global__ __launch_bounds__(TBC ? NTT_THREADS : 256, NTT_MIN_WAVES) void ntt_pa
   gl_t *dst = A.dst + ((size_t)coset * A.cols + col) * n;
   const gl_t *scale = A.scale ? A.scale + (size_t)(A.coset_first + coset * A.coset_stride) * n : nullptr;
   const uint32_t tsize = 1u << TB;
-  // lane e + i * NT of the tile: when a contiguous run (2^tb elements) divides NT = 256, the global index is
-  // linear in i (g0 + i * gstep) and so is the padded LDS index (l0 + i * 272): one add per access
+  // lane e + i * NT of the tile: when a contiguous run (2^tb elements) divides NT, the global index is linear in i
+  // (g0 + i * gstep) and so is the swizzled LDS index (l0 + i * NT: the swizzle only touches bits below log2 NT)
   constexpr int NT12 = NTT_THREADS;
   const bool glin = (1u << A.tb) <= (uint32_t)NT12;
   const uint32_t g0 = gidx(threadIdx.x, hi_base, lo0, A.s, A.tb), gstep = (NT12 >> (glin ? A.tb : 0)) << A.s;
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(TBC ? NTT_THREADS : 256, NTT_MIN_WAVES) void ntt_pa
       for (int i = 0; i < PER; i++) x[i] = gl_mul(x[i], sc[i]);
     }
 #pragma unroll
-    for (int i = 0; i < PER; i++) lds[l0 + (uint32_t)i * (NT + NT / 16)] = x[i];
+    for (int i = 0; i < PER; i++) lds[l0 + (uint32_t)i * NT] = x[i];
   } else {
     for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
       const uint32_t g = gidx(e, hi_base, lo0, A.s, A.tb);
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(TBC ? NTT_THREADS : 256, NTT_MIN_WAVES) void ntt_pa
     constexpr int PER = NTT_PER, NT = (1 << TBC) / PER;
     gl_t x[PER];
 #pragma unroll
-    for (int i = 0; i < PER; i++) x[i] = lds[l0 + (uint32_t)i * (NT + NT / 16)];
+    for (int i = 0; i < PER; i++) x[i] = lds[l0 + (uint32_t)i * NT];
     if (post) {
 #pragma unroll
       for (int i = 0; i < PER; i++) x[i] = gl_mul(x[i], A.post);
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(TBC ? NTT_THREADS : 256, NTT_MIN_WAVES) void ntt_pa
   }
 }
 
-static inline size_t lds_bytes(uint32_t TB) { return (((size_t)1 << TB) + ((size_t)1 << TB) / 16 + 1) * sizeof(gl_t); }
+static inline size_t lds_bytes(uint32_t TB) { return std::max<size_t>((size_t)1 << TB, 256) * sizeof(gl_t); }  // no padding: pidx() is a permutation of every 256-element block
 
 // ---- plan -----------------------------------------------------------------------
 // packed twiddles of one round: T[(e-1) * M + lo] = root_n^((lo * e) << (d - s0 - r)), e in [1, 2^r)

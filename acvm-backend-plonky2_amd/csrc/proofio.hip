@@ -489,7 +489,7 @@ int emit(const Out &o, uint8_t *out, size_t *out_len) {
 // the bodies of the five custom gates (their `serialize` at add_many_u32.rs:94-97, arithmetic_u32.rs:93-95,
 // comparison.rs:104-108, range_check_u32.rs:59-61, subtraction_u32.rs:87-89).  Layout written / read here
 // (usize = u64 LE, bool = u8, field = canonical u64 LE, hash = 25 bytes for KeccakHash<25> / 32 for Poseidon):
-//   usize cap_height | hash cap[2^cap_height] | hash circuit_digest
+// (VerifierCircuitData::to_bytes = write_verifier_circuit_data: CommonCircuitData FIRST, VerifierOnlyCircuitData LAST)
 //   CircuitConfig: usize num_wires, num_routed_wires, num_constants, security_bits, num_challenges,
 //                  max_quotient_degree_factor | bool use_base_arithmetic_gate, zero_knowledge | FriConfig
 //   FriConfig: usize rate_bits, cap_height, num_query_rounds | u32 proof_of_work_bits |
@@ -499,6 +499,7 @@ int emit(const Out &o, uint8_t *out, size_t *out_len) {
 //   usize quotient_degree_factor, num_gate_constraints, num_constants, num_public_inputs | usize #k_is | field k_is[]
 //   usize num_partial_products, num_lookup_polys, num_lookup_selectors | usize #luts (0)
 //   usize #gates | per gate: u32 tag | the gate's own serialize
+//   usize cap_height | hash cap[2^cap_height] | hash circuit_digest        (verifier_only)
 // The configuration constants the blob does not carry are those of CircuitConfig::wide_ecc_config
 // (circuit_translation/mod.rs:69 = standard_recursion_config with 234 / 80 wires): num_constants 2,
 // security_bits 100, max_quotient_degree_factor 8, use_base_arithmetic_gate, no zero knowledge,
@@ -547,9 +548,6 @@ void vk_write_fri_config(VkOut &o, const p2gpu_circuit *c) {
 }
 int vk_write(const p2gpu_circuit *c, VkOut &o) {
   if (c->cs.cap.size() != ((size_t)1 << c->cap_h)) { set_err("handle has no constants_sigmas cap"); return P2GPU_E_ARG; }
-  o.usize(c->cap_h);
-  for (auto &dg : c->cs.cap) o.dig(dg);
-  o.dig(c->circuit_digest);
   o.usize(c->W); o.usize(c->R); o.usize(2); o.usize(100); o.usize(c->K); o.usize(8);
   o.boolean(true); o.boolean(false);
   vk_write_fri_config(o, c);
@@ -589,6 +587,10 @@ int vk_write(const p2gpu_circuit *c, VkOut &o) {
     default: break;  // NoopGate, PoseidonGate, PublicInputGate: empty bodies
     }
   }
+  // VerifierOnlyCircuitData comes LAST (write_verifier_circuit_data: common, then verifier_only)
+  o.usize(c->cap_h);
+  for (auto &dg : c->cs.cap) o.dig(dg);
+  o.dig(c->circuit_digest);
   return P2GPU_OK;
 }
 
@@ -628,11 +630,6 @@ int vk_read(const uint8_t *bytes, size_t len, int hasher, Out &blob) {
   in.p = bytes; in.len = len;
   const size_t hb = hasher ? 32 : 25;
   auto fail = [](const char *what) { set_err("malformed verifier key: %s", what); return P2GPU_E_BLOB; };
-  const uint32_t cap_h = (uint32_t)in.usize(16);
-  if (!in.ok) return fail("cap height");
-  const uint8_t *cap = in.take(hb << cap_h);
-  const uint8_t *digest = in.take(hb);
-  if (!cap || !digest) return fail("truncated (cap / digest)");
   uint32_t h[64];
   memset(h, 0, sizeof h);
   h[0] = 0x43473250u; h[1] = 1;
@@ -645,7 +642,7 @@ int vk_read(const uint8_t *bytes, size_t len, int hasher, Out &blob) {
   if (in.boolean()) return fail("zero-knowledge circuits are not supported");
   VkFri f0, f1;
   if (!vk_read_fri_config(in, f0) || !vk_read_fri_config(in, f1)) return fail("FRI configuration");
-  if (f0.rate_bits != f1.rate_bits || f0.cap_h != f1.cap_h || f0.queries != f1.queries || f0.pow_bits != f1.pow_bits || f0.cap_h != cap_h)
+  if (f0.rate_bits != f1.rate_bits || f0.cap_h != f1.cap_h || f0.queries != f1.queries || f0.pow_bits != f1.pow_bits)
     return fail("CircuitConfig.fri_config and FriParams.config disagree");
   h[9] = f0.rate_bits; h[10] = f0.cap_h; h[11] = f0.pow_bits; h[12] = f0.queries;
   const uint32_t n_steps = (uint32_t)in.usize(8);
@@ -677,8 +674,7 @@ int vk_read(const uint8_t *bytes, size_t len, int hasher, Out &blob) {
   h[6] = 0;
   for (auto x : sel) h[6] = std::max(h[6], x + 1);  // selector columns come first in the constants table
   h[25] = 3;
-  memcpy(&h[32], digest, hb);
-  blob.put(h, sizeof h);
+  Out gate_rows;  // the header goes out first, but the digest it carries is read last
   uint32_t max_c = 0;
   for (uint32_t i = 0; i < ngates; i++) {
     const uint32_t tag = in.u32();
@@ -713,10 +709,20 @@ int vk_read(const uint8_t *bytes, size_t len, int hasher, Out &blob) {
     g[9] = deg; g[10] = nconst;
     g[8] = gate_num_constraints(g[0], &g[1]);
     max_c = std::max(max_c, g[8]);
-    blob.put(g, sizeof g);
+    gate_rows.put(g, sizeof g);
   }
-  if (in.at != in.len) return fail("trailing bytes");
   if (max_c != num_gate_constraints) return fail("num_gate_constraints does not match the gate set");
+  // VerifierOnlyCircuitData: usize cap_height | cap | circuit_digest
+  const uint32_t cap_h = (uint32_t)in.usize(16);
+  if (!in.ok) return fail("cap height");
+  if (cap_h != f0.cap_h) return fail("constants_sigmas_cap height and FriConfig.cap_height disagree");
+  const uint8_t *cap = in.take(hb << cap_h);
+  const uint8_t *digest = in.take(hb);
+  if (!cap || !digest) return fail("truncated (cap / digest)");
+  if (in.at != in.len) return fail("trailing bytes");
+  memcpy(&h[32], digest, hb);
+  blob.put(h, sizeof h);
+  blob.put(gate_rows.v.data(), gate_rows.v.size());
   for (size_t i = 0; i < ((size_t)1 << cap_h); i++) {
     uint8_t e[32];
     memset(e, 0, sizeof e);

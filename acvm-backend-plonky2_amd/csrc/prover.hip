@@ -725,9 +725,11 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     for (int i = 0; i < ch.n_in; i++) inter[i] = ch.in[i];
     // expected minimum witness ~2^pow_bits: start with 2^(pow_bits+1) candidates, then double
     uint64_t batch = 1ull << (c->pow_bits + 1 < 20 ? c->pow_bits + 1 : 20);
+    // staging words taken once: the loop may run for thousands of batches at high pow_bits
+    unsigned long long *pw = c->pin.take<unsigned long long>(2);
+    unsigned long long *allw = sharded(c) ? c->pin.take<unsigned long long>((size_t)c->shard_world) : nullptr;
+    if (!pw || (sharded(c) && !allw)) return pin_exhausted();
     for (uint64_t base = 0;; base += batch, batch = batch < (1ull << 22) ? batch * 2 : batch) {
-      unsigned long long *pw = c->pin.take<unsigned long long>(2);
-      if (!pw) return pin_exhausted();
       pw[0] = ~0ull;
       HIP_TRY(hipMemcpyAsync(c->pow_result.p, &pw[0], 8, hipMemcpyHostToDevice, st));
       // sharded: the ranks grind disjoint slices of [base, base + batch) and take the minimum of what
@@ -739,8 +741,6 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
       if (myn) pow_search(st, inter, (uint32_t)ch.n_in, c->pow_bits, my0, myn, c->pow_result.p, hprc(c));
       if (split) {
         if (int rc = shard_allgather(c, c->pow_result.p, c->xchg_recv.p, 8)) return rc;
-        unsigned long long *allw = c->pin.take<unsigned long long>((size_t)c->shard_world);
-        if (!allw) return pin_exhausted();
         HIP_TRY(hipMemcpyAsync(allw, c->xchg_recv.p, 8 * (size_t)c->shard_world, hipMemcpyDeviceToHost, st));
         g_hp.mark("enq(pow)");
         HIP_TRY(hipStreamSynchronize(st));
@@ -1283,7 +1283,11 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   {
     size_t n_final = n;
     for (uint32_t s = 0; s < c->n_steps; s++) n_final >>= c->arity[s];
-    CK(c->pin.alloc(16 * c->gather_cap + 32 * n_final + 16 * (size_t)(nall + K) * 16 + 16 * (size_t)c->nterms + 16 * (size_t)c->W + ((size_t)1 << 18)),
+    // per proof: 3 + n_steps trees stage their caps (2^cap_h digests each, twice when sharded: local roots + gathered),
+    // the alpha powers of the openings (2 * nall words), the opening partials, the final polynomial, the query gather
+    const size_t caps = (size_t)2 * (4 + c->n_steps) * (sizeof(dig_t) << c->cap_h);
+    CK(c->pin.alloc(16 * c->gather_cap + 32 * n_final + 16 * (size_t)(nall + K) * 16 + 16 * (size_t)nall + 16 * (size_t)c->nterms +
+                    16 * (size_t)c->W + caps + ((size_t)1 << 18)),
        "alloc pinned staging");
   }
 
@@ -1724,7 +1728,7 @@ int p2gpu_commit_values(const uint64_t *vals, size_t ncols, unsigned d, unsigned
   do {
     if (hipStreamCreate(&c->stream) != hipSuccess || c->tw_fwd.alloc(half) != hipSuccess ||
         c->tw_inv.alloc(half) != hipSuccess || c->scale.alloc((size_t)c->C * n) != hipSuccess ||
-        c->wires_vals.alloc(ncols * n) != hipSuccess || c->pin.alloc((size_t)1 << 16) != hipSuccess) {
+        c->wires_vals.alloc(ncols * n) != hipSuccess || c->pin.alloc(((size_t)1 << 16) + 2 * (sizeof(dig_t) << cap_h)) != hipSuccess) {
       set_err("hipMalloc failed");
       rc = P2GPU_E_DEVICE;
       break;

@@ -122,6 +122,17 @@ int p2gpu_verifier_create(const uint8_t *blob, size_t len, p2gpu_circuit **out) 
     memset(&c->cs.cap[i], 0, sizeof(dig_t));
     memcpy(c->cs.cap[i].w, cap_in + 32 * i, c->hasher ? 32 : 25);
   }
+  if (c->hasher) {  // Poseidon digests are field elements: canonical encodings only (as Cursor::digest() asks of a proof)
+    bool canon = true;
+    for (auto &dg : c->cs.cap)
+      for (int i = 0; i < 4; i++) canon &= dg.w[i] < GL_P;
+    for (int i = 0; i < 4; i++) canon &= c->circuit_digest.w[i] < GL_P;
+    if (!canon) {
+      delete c;
+      set_err("verifier key holds a non-canonical Poseidon digest word");
+      return P2GPU_E_BLOB;
+    }
+  }
   c->device = -1;  // no device state: only p2gpu_verify and the getters accept this handle
   *out = c;
   return P2GPU_OK;

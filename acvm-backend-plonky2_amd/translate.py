@@ -41,6 +41,7 @@ class CircuitBuilder:
         self.const_of, self.consts = {}, {}
         self.rows = []            # gate instances in creation order
         self.free_arith = {}      # (c0, c1) -> row with a free slot
+        self.arith_results = {}   # (c0, c1, m0, m1, addend) -> output target of the identical earlier operation
         self.events = []          # witness generators in creation order
         self.rng = np.random.default_rng(seed)
 
@@ -112,6 +113,12 @@ class CircuitBuilder:
                 return m1
             if k1 is not None and k1 * c0 % P == 1:
                 return m0
+        # plonky2's `base_arithmetic_results`: an identical operation (same constants, same targets) returns the earlier
+        # output instead of a fresh ArithmeticGate slot (gadgets/arithmetic.rs CircuitBuilder::arithmetic)
+        op = (c0, c1, m0, m1, addend)
+        cached = self.arith_results.get(op)
+        if cached is not None:
+            return cached
         key = (c0, c1)
         r = self.free_arith.get(key)
         if r is None or len(self.rows[r]["ops"]) == NUM_OPS:
@@ -121,6 +128,7 @@ class CircuitBuilder:
         out = self.add_virtual_target()
         self.rows[r]["ops"].append((m0, m1, addend, out))
         self.events.append(("arith", c0, c1, m0, m1, addend, out))
+        self.arith_results[op] = out
         return out
 
     def mul(self, x, y):

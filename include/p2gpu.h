@@ -206,7 +206,9 @@ int p2gpu_verify_compressed(const p2gpu_circuit *c, const uint8_t *cproof, size_
  * launches with HIP events on the launch stream -- 1 = the launches that move >= 32 MB, 2 = every launch;
  * resets the statistics), "zero_columns" (0/1, default 1: one pass over the witness finds the wire columns that
  * are zero in every row -- the wires no gate of the circuit uses -- and stores zeros instead of running their
- * inverse transform and LDE; the proof bytes do not depend on it) */
+ * inverse transform and LDE; the proof bytes do not depend on it), "virtual_columns" (0/1, default 1: structured
+ * wire columns that only the leaf hash and the query gather read are never stored -- both recompute them as scalar x
+ * LDE(unit column); the proof bytes do not depend on it) */
 int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value);
 /* statistics accumulated while "profile" = 1, one entry per kernel symbol:
  * names[64*i] (NUL-terminated), total milliseconds, total algorithmic bytes,
@@ -246,12 +248,12 @@ int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned r
 int p2gpu_commit_values(const uint64_t *vals, size_t ncols, unsigned d, unsigned rate_bits, unsigned cap_h,
                         uint8_t *cap_out);
 /* KeccakHash<25>::hash_no_pad of `n_rows` rows of `row_len` elements (row-major) -> n_rows x 25 B */
+int p2gpu_hash_rows(const uint64_t *rows, size_t n_rows, size_t row_len, uint8_t *digests_out);
 /* Self-test of the device field arithmetic (the carry-chain forms of csrc/gl.hpp and the NTT's power-of-two
  * multipliers) against the portable code the host and the oracle run, on the n pairs (a[i], b[i]) of arbitrary
  * 64-bit words.  bad_out[k] = mismatches of: 0 canon, 1 add, 2 sub, 3 reduce128, 4 mul, 5 mul_add,
  * 6 x * 2^e for e = 1..95, 7 the 160-bit accumulator.  All zero on a correct build. */
 int p2gpu_field_selftest(const uint64_t *a, const uint64_t *b, size_t n, uint64_t bad_out[8]);
-int p2gpu_hash_rows(const uint64_t *rows, size_t n_rows, size_t row_len, uint8_t *digests_out);
 
 const char *p2gpu_last_error(void);
 /* name/arch of the device in use, and peak numbers the bench prints */

@@ -475,7 +475,9 @@ def test_standalone_c_caller(pkg, orc, gpu, tmp_path):
     assert r.returncode == 0, r.stderr
     hx = (tmp_path / "p.hex").read_text()
     assert len(hx) // 2 < len(expect) and bytes.fromhex(hx)[:25] == expect[:25]
-    assert (tmp_path / "vk.ref").read_bytes()[:8] == (4).to_bytes(8, "little")  # usize cap_height first
+    # CommonCircuitData first (usize config.num_wires), VerifierOnlyCircuitData (cap height, cap, digest) last
+    vkref = (tmp_path / "vk.ref").read_bytes()
+    assert vkref[:8] == (234).to_bytes(8, "little") and vkref[-(8 + 17 * 25):][:8] == (4).to_bytes(8, "little")
     for key in ("vk.blob", "vk.ref"):
         r = subprocess.run([vexe, str(tmp_path / key), str(tmp_path / "p.hex")], capture_output=True, text=True, timeout=60)
         assert r.returncode == 0 and "accepted" in r.stderr, r.stderr

@@ -234,8 +234,8 @@ def test_reference_vk_file_format_round_trip(pkg, orc, d, mix, seed, npi, nw, ha
     """`write_vk` / `verify` of the reference exchange `VerifierCircuitData::to_bytes(&BackendGateSerializer)`
     (write_vk_action.rs:77-80, noir_and_plonky2_serialization.rs:16-22).  The restatement is UNPINNED (no VK file
     in the reference tree); what is tested: export -> import is lossless (same verifier blob, same bytes again),
-    the imported key accepts the oracle's proof and rejects a tampered one, the layout's fixed points (cap height,
-    cap, digest, wide_ecc_config constants, gate tags of write_vk_action.rs:39-61) sit where the layout says."""
+    the imported key accepts the oracle's proof and rejects a tampered one, the layout's fixed points (wide_ecc_config constants,
+    cap height, cap, digest at the end, gate tags of write_vk_action.rs:39-61) sit where the layout says."""
     oc, vd, wires, pis = make(pkg, orc, d, mix, seed, npi, nw, hasher=hasher)
     proof, _ = oc.prove(wires, public_inputs=pis)
     vk = vd.to_plonky2_bytes()
@@ -249,8 +249,10 @@ def test_reference_vk_file_format_round_trip(pkg, orc, d, mix, seed, npi, nw, ha
         vd2.verify(bytes(bad))
     hb = 32 if hasher else 25
     u64 = lambda off: int.from_bytes(vk[off:off + 8], "little")
-    assert u64(0) == 4 and vk[8:8 + 16 * hb] == oc.cap() and vk[8 + 16 * hb:8 + 17 * hb] == oc.digest()
-    cfg = 8 + 17 * hb
+    # VerifierCircuitData::to_bytes = CommonCircuitData first, VerifierOnlyCircuitData (cap height, cap, digest) last
+    vo = len(vk) - (8 + 17 * hb)
+    assert u64(vo) == 4 and vk[vo + 8:vo + 8 + 16 * hb] == oc.cap() and vk[vo + 8 + 16 * hb:] == oc.digest()
+    cfg = 0
     assert [u64(cfg + 8 * i) for i in range(6)] == [nw, 80, 2, 100, 2, 8] and vk[cfg + 48:cfg + 50] == b"\x01\x00"
     # FriConfig: rate_bits 3, cap_height 4, 28 queries, 16 PoW bits, ConstantArityBits(4, 5)
     fri = cfg + 50
@@ -259,7 +261,7 @@ def test_reference_vk_file_format_round_trip(pkg, orc, d, mix, seed, npi, nw, ha
     # truncations and bit flips never crash the reader: rejected, or parsed into some key (configuration words the
     # blob does not keep, e.g. security_bits, may change without changing the key)
     rng = np.random.default_rng(seed)
-    for cut in [0, 7, 8, cfg, fri + 10, len(vk) - 1]:
+    for cut in [0, 7, 8, fri + 10, vo, vo + 8, len(vk) - 1]:
         with pytest.raises(pkg.P2GpuError):
             pkg.VerifierCircuitData.from_plonky2_bytes(vk[:cut], hasher=hasher)
     for _ in range(60):

@@ -17,6 +17,7 @@ from .prover import (  # noqa: F401
     ProofWithPublicInputs,
     P2GpuError,
     device_info,
+    init,
     ifft_batch,
     lde_batch,
     commit_values,

@@ -12,6 +12,7 @@
 
 #include <exception>
 
+struct p2gpu_circuit;
 namespace p2 {
 
 // thread-local message behind p2gpu_last_error() (hostcore.hip)
@@ -245,6 +246,7 @@ struct CircuitState {
   std::vector<Batch> fri_trees;  // only dig/level_off/cap used
   DBuf<unsigned long long> pow_result;
   PinnedArena pin;
+  uint64_t *tail_stage = nullptr;  // pinned [W]: row values of the unused-wire suffix the host scan of p2gpu_prove found
   DBuf<uint64_t> gather_ptrs;
   DBuf<gl_t> gather_out;
   size_t gather_cap = 0;
@@ -255,6 +257,12 @@ struct CircuitState {
   void *rccl_comm = nullptr;              // ncclComm_t: RCCL transport, collectives on `stream`
   int shard_exercise = 0;                 // run the exchange steps even with world = 1 (plumbing test)
   DBuf<gl_t> xchg_recv;
+  // ONE process driving several GPUs (p2gpu_init with n > 1 device ids): the handle the caller holds is rank 0 of a
+  // group and owns ranks 1..; every prove call fans out over one host thread per rank, and the exchanges of the
+  // sharded proof are peer-to-peer copies between the ranks' own streams (PeerGroup, prover.hip) -- no RCCL, no
+  // second process, which is the shape the reference's single `prove` call site (prove_action.rs:96) can drive
+  std::vector<p2gpu_circuit *> group;     // ranks 1..world-1 (empty: an ordinary handle)
+  struct PeerGroup *peer = nullptr;       // shared by the ranks of a group, owned by rank 0
   // knobs
   uint64_t pow_hint = UINT64_MAX;
   int profile = 0;

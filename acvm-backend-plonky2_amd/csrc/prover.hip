@@ -13,12 +13,16 @@
 #include <rccl/rccl.h>  // types and prototypes only: resolved with dlopen, never linked
 #include <dlfcn.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace p2;
@@ -187,11 +191,82 @@ const RcclApi &rccl() {
     }                                                                                             \
   } while (0)
 
+}  // namespace
+namespace p2 {
+// The ranks of ONE process (p2gpu_init with several device ids): a host rendezvous for the rank threads and two
+// events per rank.  An all-gather is `world` peer copies per rank, each enqueued on the SENDING rank's own stream
+// straight into the receiver's buffer (hipMemcpyPeerAsync: xGMI on a multi-GPU node, and every rank drives all its
+// links at once -- SURVEY 8(e) step 2's "not a ring"); readiness travels as events, never as a host wait:
+//   recv_free[p]  recorded by p before the exchange: everything p enqueued that still reads its receive buffer
+//   sent[q]       recorded by q behind its copies: p's consumers wait for all of them
+// The two host barriers only order the event RECORDS before the cross-stream WAITS that name them.
+struct PeerGroup {
+  int n = 0;
+  std::vector<p2gpu_circuit *> cs;
+  std::vector<hipEvent_t> recv_free, sent;
+  std::vector<const void *> send_ptr;
+  std::vector<void *> recv_ptr;
+  std::mutex m;
+  std::condition_variable cv;
+  int waiting = 0;
+  uint64_t gen = 0;
+  bool aborted = false;
+  bool barrier() {
+    std::unique_lock<std::mutex> l(m);
+    if (aborted) return false;
+    const uint64_t g = gen;
+    if (++waiting == n) {
+      waiting = 0;
+      gen++;
+      cv.notify_all();
+      return true;
+    }
+    cv.wait(l, [&] { return gen != g || aborted; });
+    return gen != g;
+  }
+  void abort() {  // a rank left the proof with an error: nobody may wait for it
+    std::lock_guard<std::mutex> l(m);
+    aborted = true;
+    cv.notify_all();
+  }
+  void reset() {
+    std::lock_guard<std::mutex> l(m);
+    aborted = false;
+    waiting = 0;
+  }
+};
+}  // namespace p2
+namespace {
+int peer_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size_t bytes) {
+  PeerGroup &g = *c->peer;
+  const int q = c->shard_rank;
+  auto failed = [] {
+    set_err("another rank of the device group failed");
+    return P2GPU_E_DEVICE;
+  };
+  g.send_ptr[q] = send_dev;
+  g.recv_ptr[q] = recv_dev;
+  HIP_TRY(hipEventRecord(g.recv_free[q], c->stream));
+  if (!g.barrier()) return failed();
+  for (int p = 0; p < g.n; p++) {
+    if (p != q) HIP_TRY(hipStreamWaitEvent(c->stream, g.recv_free[p], 0));
+    uint8_t *dst = (uint8_t *)g.recv_ptr[p] + (size_t)q * bytes;
+    if ((const void *)dst != send_dev)  // (an in-place all-gather already has the rank's own block where it belongs)
+      HIP_TRY(hipMemcpyPeerAsync(dst, g.cs[p]->device, send_dev, c->device, bytes, c->stream));
+  }
+  HIP_TRY(hipEventRecord(g.sent[q], c->stream));
+  if (!g.barrier()) return failed();
+  for (int p = 0; p < g.n; p++)
+    if (p != q) HIP_TRY(hipStreamWaitEvent(c->stream, g.sent[p], 0));
+  return 0;
+}
+
 // all-gather over the ranks of a sharded proof, device buffers, recv = [world][bytes].  With an RCCL
 // communicator (p2gpu_circuit_set_shard_rccl) it is an ncclAllGather enqueued on the circuit's stream;
 // with a host callback (p2gpu_circuit_set_shard: gloo in the CPU-side tests) the stream is drained and
 // the callback returns when the data is in place.
 int shard_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size_t bytes) {
+  if (c->peer) return peer_allgather(c, send_dev, recv_dev, bytes);
   if (c->rccl_comm) {
     RCCL_TRY(rccl().AllGather(send_dev, recv_dev, bytes, ncclUint8, (ncclComm_t)c->rccl_comm, c->stream));
     return 0;
@@ -206,7 +281,7 @@ int shard_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size
 }
 // does this proof go through the exchange steps?  (world 1 + "shard_exercise": the same code with one
 // rank, which is how the RCCL plumbing is exercised on a single-GPU box)
-bool sharded(const p2gpu_circuit *c) { return c->shard_world > 1 || (c->shard_exercise && (c->rccl_comm || c->shard_fn)); }
+bool sharded(const p2gpu_circuit *c) { return c->shard_world > 1 || (c->shard_exercise && (c->rccl_comm || c->shard_fn || c->peer)); }
 
 int pin_exhausted() {
   set_err("internal: pinned staging arena exhausted");
@@ -951,6 +1026,8 @@ void circuit_release(p2gpu_circuit *c) {
   c->wire_clean.release();
   c->wire_scalar.release(); c->sparse_coeffs.release(); c->sparse_lde.release(); c->sparse_partial.release();
   c->pin.release();
+  if (c->tail_stage) (void)hipHostFree(c->tail_stage);
+  c->tail_stage = nullptr;
   c->pow_result.release(); c->gather_ptrs.release(); c->gather_out.release(); c->xchg_recv.release();
   ntt_plan_destroy(c->plan_inv);
   ntt_plan_destroy(c->plan_fwd);
@@ -966,6 +1043,19 @@ void circuit_release(p2gpu_circuit *c) {
 
 // hostcore.hip's p2gpu_circuit_destroy calls this for prover handles (it has no HIP code of its own)
 void release_for_destroy(p2gpu_circuit *c) {
+  // rank 0 of a device group owns the other ranks and the rendezvous
+  for (p2gpu_circuit *m : c->group) {
+    m->peer = nullptr;
+    release_for_destroy(m);
+    delete m;
+  }
+  c->group.clear();
+  if (c->peer && c->shard_rank == 0) {
+    for (auto e : c->peer->recv_free) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->peer->sent) if (e) (void)hipEventDestroy(e);
+    delete c->peer;
+  }
+  c->peer = nullptr;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->rccl_comm) (void)rccl().CommDestroy((ncclComm_t)c->rccl_comm);
@@ -977,6 +1067,7 @@ struct ReleaseHook {
 } g_release_hook;
 
 int g_device = -1;
+std::vector<int> g_devices;  // p2gpu_init's list; more than one entry: circuit handles are device groups
 
 int ensure_device() {
   if (g_device >= 0) return 0;
@@ -1027,19 +1118,33 @@ int p2gpu_init(const int *device_ids, int n_devices) {
     set_err("no HIP device available (%s); libp2gpu has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
     return P2GPU_E_DEVICE;
   }
-  // one process per GPU: exactly one device per process; more than one id is a caller
-  // bug, not something to ignore silently
-  if (device_ids && n_devices > 1) {
-    set_err("p2gpu_init: %d device ids given; this library runs one process per GPU (pass one id)", n_devices);
+  // One id: one process per GPU (replicas, or ranks of an RCCL-sharded proof).  Several ids: THIS process drives them
+  // all -- every circuit handle created from now on is a device group, and each prove call is one proof coset-sharded
+  // over the group; the count must divide the 2^rate_bits cosets of the circuits (checked at create).
+  // The same id may appear more than once: those ranks then share a GPU, which is how the group path is tested on a
+  // one-GPU box (functionally identical, no speed-up).
+  if (n_devices > 8) {
+    set_err("p2gpu_init: %d device ids (at most 8: one per LDE coset)", n_devices);
     return P2GPU_E_ARG;
   }
-  int dev = (device_ids && n_devices > 0) ? device_ids[0] : 0;
-  if (dev < 0 || dev >= cnt) {
-    set_err("device id %d out of range (%d devices)", dev, cnt);
-    return P2GPU_E_ARG;
-  }
-  HIP_TRY(hipSetDevice(dev));
-  g_device = dev;
+  std::vector<int> devs;
+  for (int i = 0; i < (device_ids ? n_devices : 0); i++) devs.push_back(device_ids[i]);
+  if (devs.empty()) devs.push_back(0);
+  for (int dev : devs)
+    if (dev < 0 || dev >= cnt) {
+      set_err("device id %d out of range (%d devices)", dev, cnt);
+      return P2GPU_E_ARG;
+    }
+  for (size_t a = 0; a < devs.size(); a++)
+    for (size_t b = 0; b < devs.size(); b++)
+      if (devs[a] != devs[b]) {  // direct peer copies over xGMI; "already enabled" and "not supported" are not errors here
+        (void)hipSetDevice(devs[a]);
+        (void)hipDeviceEnablePeerAccess(devs[b], 0);
+        (void)hipGetLastError();
+      }
+  HIP_TRY(hipSetDevice(devs[0]));
+  g_device = devs[0];
+  g_devices = devs;
   return P2GPU_OK;
 }
 
@@ -1054,9 +1159,107 @@ int p2gpu_device_info(char *name_out, size_t name_cap, int *cu_count, size_t *hb
 }
 
 
+static int shard_layout(p2gpu_circuit *c, int rank, int world);
+static int shard_args_ok(p2gpu_circuit *c, int rank, int world);
+static int circuit_create_one(const uint8_t *blob, size_t len, int device, p2gpu_circuit **out_c);
+
+// run f(rank handle, rank) on one host thread per rank of a device group (rank 0 on the caller's thread); a rank
+// that fails releases the others from their rendezvous.  Returns the first failing rank's code with its message.
+extern "C++" {
+template <class F>
+static int group_run(p2gpu_circuit *c, F f) {
+  const int n = 1 + (int)c->group.size();
+  std::vector<int> rcs(n, 0);
+  std::vector<std::string> errs(n);
+  c->peer->reset();
+  auto work = [&](int q) {
+    p2gpu_circuit *m = q ? c->group[q - 1] : c;
+    int rc;
+    try {
+      rc = f(m, q);
+    } catch (const std::exception &e) {
+      set_err("internal error: %s", e.what());
+      rc = P2GPU_E_DEVICE;
+    }
+    if (rc) {
+      errs[q] = p2gpu_last_error();
+      c->peer->abort();
+    }
+    rcs[q] = rc;
+  };
+  std::vector<std::thread> th;
+  for (int q = 1; q < n; q++) th.emplace_back(work, q);
+  work(0);
+  for (auto &t : th) t.join();
+  (void)hipSetDevice(c->device);
+  // prefer the code of a rank that failed on its own over "another rank failed"
+  int first = -1;
+  for (int q = 0; q < n; q++)
+    if (rcs[q] && (first < 0 || (errs[first].find("another rank") != std::string::npos && errs[q].find("another rank") == std::string::npos))) first = q;
+  if (first < 0) return P2GPU_OK;
+  set_err("%s%s", errs[first].c_str(), n > 1 ? (" (device group rank " + std::to_string(first) + ")").c_str() : "");
+  return rcs[first];
+}
+}  // extern "C++"
+
 int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c) try {
   if (!blob || !out_c) return P2GPU_E_ARG;
   if (int rc = ensure_device()) return rc;
+  if (g_devices.size() <= 1) return circuit_create_one(blob, len, g_device, out_c);
+  // a device group: one full handle per device (each commits constants / sigmas for itself: 5 ms), then the coset
+  // layout of rank q of n on each and the shared rendezvous
+  const int n = (int)g_devices.size();
+  std::vector<p2gpu_circuit *> hs(n, nullptr);
+  std::vector<int> rcs(n, 0);
+  std::vector<std::string> errs(n);
+  {
+    std::vector<std::thread> th;
+    for (int q = 0; q < n; q++)
+      th.emplace_back([&, q] {
+        rcs[q] = circuit_create_one(blob, len, g_devices[q], &hs[q]);
+        if (rcs[q]) errs[q] = p2gpu_last_error();
+      });
+    for (auto &t : th) t.join();
+  }
+  (void)hipSetDevice(g_device);
+  auto drop = [&](int rc, const std::string &msg) {
+    for (auto *h : hs)
+      if (h) {
+        h->peer = nullptr;
+        p2gpu_circuit_destroy(h);
+      }
+    set_err("%s", msg.c_str());
+    return rc;
+  };
+  for (int q = 0; q < n; q++)
+    if (rcs[q]) return drop(rcs[q], errs[q]);
+  for (int q = 0; q < n; q++) {
+    if (int rc = shard_args_ok(hs[q], q, n)) return drop(rc, p2gpu_last_error());
+    if (int rc = shard_layout(hs[q], q, n)) return drop(rc, p2gpu_last_error());
+  }
+  PeerGroup *pg = new PeerGroup();
+  pg->n = n;
+  pg->cs = hs;
+  pg->recv_free.resize(n);
+  pg->sent.resize(n);
+  pg->send_ptr.resize(n);
+  pg->recv_ptr.resize(n);
+  for (int q = 0; q < n; q++) {
+    (void)hipSetDevice(hs[q]->device);
+    if (hipEventCreateWithFlags(&pg->recv_free[q], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&pg->sent[q], hipEventDisableTiming) != hipSuccess) {
+      delete pg;
+      return drop(P2GPU_E_DEVICE, "hipEventCreate failed");
+    }
+    hs[q]->peer = pg;
+  }
+  (void)hipSetDevice(g_device);
+  for (int q = 1; q < n; q++) hs[0]->group.push_back(hs[q]);
+  *out_c = hs[0];
+  return P2GPU_OK;
+} P2GPU_CATCH
+
+static int circuit_create_one(const uint8_t *blob, size_t len, int device, p2gpu_circuit **out_c) try {
   p2gpu_circuit *c = new p2gpu_circuit();
   size_t off = 0;
   const uint8_t *cap_in = nullptr;
@@ -1064,7 +1267,7 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
     delete c;
     return rc;
   }
-  c->device = g_device;
+  c->device = device;
   auto fail = [&](int rc, const char *msg) {
     set_err("%s", msg);
     circuit_release(c);
@@ -1344,6 +1547,9 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
 int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
   if (!c || !key) return P2GPU_E_ARG;
   if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
+  for (p2gpu_circuit *m : c->group)  // a device group: every rank gets the same knobs (the ranks must take the same path)
+    if (int rc = p2gpu_circuit_set(m, key, value)) return rc;
+  HIP_TRY(hipSetDevice(c->device));
   std::string k(key);
   if (k == "pow_hint") c->pow_hint = value;
   else if (k == "self_check") c->self_check = (int)value;
@@ -1416,7 +1622,12 @@ static int shard_args_ok(p2gpu_circuit *c, int rank, int world) {
   return P2GPU_OK;
 }
 
+static int not_a_group(const p2gpu_circuit *c) {
+  if (c && c->peer) { set_err("this handle is a device group of one process (p2gpu_init with several ids): its sharding is fixed"); return P2GPU_E_ARG; }
+  return P2GPU_OK;
+}
 int p2gpu_circuit_set_shard(p2gpu_circuit *c, int rank, int world, p2gpu_allgather_fn fn, void *ctx) try {
+  if (int rc = not_a_group(c)) return rc;
   if (int rc = shard_args_ok(c, rank, world)) return rc;
   if (world > 1 && !fn) { set_err("a host all-gather callback is needed for world > 1 (or use p2gpu_circuit_set_shard_rccl)"); return P2GPU_E_ARG; }
   if (int rc = shard_layout(c, rank, world)) return rc;
@@ -1437,6 +1648,7 @@ int p2gpu_shard_unique_id(uint8_t id_out[128]) try {
 } P2GPU_CATCH
 
 int p2gpu_circuit_set_shard_rccl(p2gpu_circuit *c, int rank, int world, const uint8_t id_in[128]) try {
+  if (int rc = not_a_group(c)) return rc;
   if (int rc = shard_args_ok(c, rank, world)) return rc;
   if (!id_in) return P2GPU_E_ARG;
   if (!rccl().ok) { set_err("librccl.so.1 could not be loaded"); return P2GPU_E_DEVICE; }
@@ -1479,10 +1691,35 @@ int p2gpu_fill_witness(p2gpu_circuit *c, uint64_t *wires_dev) try {
   return P2GPU_OK;
 } P2GPU_CATCH
 
+// A device group proves by running the same entry point on every rank, one host thread each; every rank returns the
+// same bytes, rank 0's go to the caller.
+extern "C++" {
+template <class F>
+static int group_prove(p2gpu_circuit *c, uint8_t *proof_out, size_t *proof_len, p2gpu_timings *tm, F f) {
+  const size_t cap = *proof_len;
+  std::vector<std::vector<uint8_t>> scratch(c->group.size());
+  std::vector<size_t> lens(c->group.size(), cap);
+  return group_run(c, [&](p2gpu_circuit *m, int q) {
+    if (q == 0) return f(m, q, proof_out, proof_len, tm);
+    scratch[q - 1].resize(cap);
+    return f(m, q, scratch[q - 1].data(), &lens[q - 1], (p2gpu_timings *)nullptr);
+  });
+}
+}  // extern "C++"
+static int prove_routed_one(p2gpu_circuit *c, const uint64_t *routed, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
+                            size_t *proof_len, p2gpu_timings *tm);
 int p2gpu_prove_routed(p2gpu_circuit *c, const uint64_t *routed, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
                        size_t *proof_len, p2gpu_timings *tm) try {
   if (!c || !routed || !proof_out || !proof_len) return P2GPU_E_ARG;
   if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
+  if (!c->group.empty())
+    return group_prove(c, proof_out, proof_len, tm, [&](p2gpu_circuit *m, int, uint8_t *po, size_t *pl, p2gpu_timings *t) {
+      return prove_routed_one(m, routed, pis, n_pi, po, pl, t);
+    });
+  return prove_routed_one(c, routed, pis, n_pi, proof_out, proof_len, tm);
+} P2GPU_CATCH
+static int prove_routed_one(p2gpu_circuit *c, const uint64_t *routed, const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out,
+                            size_t *proof_len, p2gpu_timings *tm) try {
   HIP_TRY(hipSetDevice(c->device));
   double t0 = now_ms();
   // only the routed columns cross PCIe; every other column is gate-internal and derived on the GPU
@@ -1499,22 +1736,122 @@ int p2gpu_prove_dev(p2gpu_circuit *c, const uint64_t *wires_dev, const uint64_t 
                     size_t *proof_len, p2gpu_timings *tm) try {
   if (!c || !wires_dev || !proof_out || !proof_len) return P2GPU_E_ARG;
   if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
+  if (!c->group.empty())
+    // the witness is resident on rank 0's device: the other ranks pull it over the peer link into their own staging
+    // buffer (the host-witness entry points shard the upload instead: each rank fetches 1/world of it over its own PCIe link)
+    return group_prove(c, proof_out, proof_len, tm, [&](p2gpu_circuit *m, int, uint8_t *po, size_t *pl, p2gpu_timings *t) {
+      const uint64_t *w = wires_dev;
+      if (m->device != c->device) {
+        HIP_TRY(hipSetDevice(m->device));
+        HIP_TRY(hipMemcpyPeerAsync(m->wires_vals.p, m->device, wires_dev, c->device, 8 * (size_t)m->W * m->n, m->stream));
+        w = m->wires_vals.p;
+      }
+      return prove_impl(m, w, pis, n_pi, po, pl, t, 0.0);
+    });
   return prove_impl(c, wires_dev, pis, n_pi, proof_out, proof_len, tm, 0.0);
 } P2GPU_CATCH
+
+// Host-side look at the witness of the full-matrix entry point (p2gpu_prove): the longest SUFFIX of columns that are
+// zero outside `row` -- the wires no gate of the circuit uses, which plonky2's build() leaves at zero except for one random
+// value in the PublicInputGate row.  They need not cross PCIe (154 of 234 columns, 161 of 245 MB, for a circuit without
+// ECC gates): what p2gpu_prove_sparse lets a caller say, found here by looking.  A few host threads read the columns from
+// the last one down and stop at the first column that is dense (a dense witness costs a few cache lines); the scan runs
+// while the first chunks (columns below the routed-wire count) are already crossing PCIe.
+struct HostScan {
+  uint32_t ncols = 0;            // columns [ncols, W) are zero outside `row`
+  std::vector<uint64_t> tail;    // their values in `row`
+};
+static void host_scan_suffix(const uint64_t *wires, uint32_t W, size_t n, uint32_t row, uint32_t lo, HostScan *out) {
+  // several proofs may be in flight, each with its own scan: a quarter of the CPUs this process may use (the cgroup
+  // quota where there is one: the MI355X boxes show 256 hardware threads and grant 16 CPUs), at most 8
+  static const unsigned T = [] {
+    unsigned n = std::thread::hardware_concurrency();
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      long long q = 0, per = 0;
+      if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, q / per));
+      fclose(f);
+    }
+    n /= 4;
+    return n < 1 ? 1u : (n > 8 ? 8u : n);
+  }();
+  std::atomic<uint32_t> dense_max{lo};  // columns below this one are not worth looking at any more
+  std::vector<uint8_t> sparse(W, 0);
+  auto work = [&](unsigned t) {
+    for (int64_t j = (int64_t)W - 1 - t; j >= (int64_t)lo; j -= T) {
+      if ((uint32_t)j < dense_max.load(std::memory_order_relaxed)) break;
+      const uint64_t *p = wires + (size_t)j * n;
+      bool zero = true;
+      for (size_t b = 0; b < n && zero; b += 2048) {  // 16 KB at a time: early exit on a dense column
+        const size_t e = std::min(n, b + 2048);
+        uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        size_t i = b;
+        for (; i + 4 <= e; i += 4) { a0 |= p[i]; a1 |= p[i + 1]; a2 |= p[i + 2]; a3 |= p[i + 3]; }
+        for (; i < e; i++) a0 |= p[i];
+        uint64_t acc = a0 | a1 | a2 | a3;
+        if (acc && row >= b && row < e) {  // the block holding the special row: look again without it
+          acc = 0;
+          for (size_t k = b; k < e; k++) acc |= (k == row) ? 0 : p[k];
+        }
+        zero = acc == 0;
+      }
+      if (zero) sparse[j] = 1;
+      else {
+        uint32_t cur = dense_max.load(std::memory_order_relaxed);
+        while ((uint32_t)j + 1 > cur && !dense_max.compare_exchange_weak(cur, (uint32_t)j + 1, std::memory_order_relaxed)) {}
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < T; t++) th.emplace_back(work, t);
+  work(0);
+  for (auto &x : th) x.join();
+  uint32_t nc = W;
+  while (nc > lo && sparse[nc - 1]) nc--;
+  out->ncols = nc;
+  out->tail.resize(W - nc);
+  for (uint32_t j = nc; j < W; j++) out->tail[j - nc] = row < n ? wires[(size_t)j * n + row] : 0;
+}
+static bool host_prescan_on() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("P2GPU_HOST_PRESCAN");  // 0: ship the whole matrix as rounds 1-2 did (for A/B measurements)
+    v = (e && *e == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
 
 // p2gpu_prove (ncols = W) and p2gpu_prove_sparse (ncols < W: the columns >= ncols are zero except in `row`, where
 // column j holds tail[j - ncols]; they are written in HBM instead of crossing PCIe)
 static int prove_host(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, const uint64_t *tail, uint32_t row,
                       const uint64_t *pis, uint32_t n_pi, uint8_t *proof_out, size_t *proof_len, p2gpu_timings *tm) {
   HIP_TRY(hipSetDevice(c->device));
-  if (ncols < c->W) {
-    // the unused wires of the witness: zeros + one value per column, made on the device (stream-ordered before
-    // every consumer below; the host part of the matrix arrives on the copy stream into the columns before them)
+  // the unused wires of the witness: zeros + one value per column, made on the device (stream-ordered before
+  // every consumer below; the host part of the matrix arrives on the copy stream into the columns before them)
+  auto make_tail = [&]() -> int {
+    if (ncols >= c->W) return 0;
     const uint32_t nt = c->W - ncols;
     gl_t *tv = c->wires_vals.p + (size_t)ncols * c->n;
     HIP_TRY(hipMemsetAsync(tv, 0, 8 * (size_t)nt * c->n, c->stream));
     HIP_TRY(hipMemcpy2DAsync(tv + row, 8 * c->n, tail, 8, 8, nt, hipMemcpyHostToDevice, c->stream));
+    return 0;
+  };
+  // full matrix given: look for the unused-wire suffix on the host while the first chunks upload (see host_scan_suffix).
+  // Only where it can pay: the handle still classifies columns (a handle that found a dense witness stopped), and the
+  // witness of a sharded proof is split by columns anyway.
+  HostScan scan;
+  std::thread scan_thread;
+  bool scanning = false;
+  uint64_t *tail_pinned = nullptr;
+  if (ncols == c->W && c->zero_columns && !c->structured_off && c->shard_world == 1 && host_prescan_on() && c->W > c->R) {
+    row = c->sparse_row != UINT32_MAX ? c->sparse_row : 0;
+    scan_thread = std::thread(host_scan_suffix, wires, c->W, c->n, row, c->R, &scan);
+    scanning = true;
   }
+  struct Joiner {  // never leave the function with the scan still running
+    std::thread &t;
+    ~Joiner() { if (t.joinable()) t.join(); }
+  } joiner{scan_thread};
+  if (int rc = make_tail()) return rc;
   // The witness crosses PCIe in column chunks on a copy stream; the inverse transform and the
   // LDE of a chunk run while the next chunk is still in flight (values -> coefficients -> LDE are
   // per-column; only the leaf hash needs every column).
@@ -1567,6 +1904,21 @@ static int prove_host(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, c
   const uint32_t full_blocks = W / 17;
   uint32_t ci = 0;
   for (uint32_t col0 = 0, nc = 0; col0 < W; col0 += nc, ci++) {
+    if (scanning && col0 + chunk > c->R) {
+      // the first chunk that reaches beyond the routed wires: the host scan decides what is left to upload.  Columns
+      // already enqueued stay as they are (ncols never drops below col0)
+      scan_thread.join();
+      scanning = false;
+      if (scan.ncols < W) {
+        ncols = std::max(scan.ncols, col0);
+        // the 2-D copy below is asynchronous: its source must outlive this frame AND prove_impl's reset of the pinned arena
+        if (!c->tail_stage) HIP_TRY(hipHostMalloc((void **)&c->tail_stage, 8 * (size_t)W, hipHostMallocDefault));
+        tail_pinned = c->tail_stage;
+        memcpy(tail_pinned, scan.tail.data() + (ncols - scan.ncols), 8 * (size_t)(W - ncols));
+        tail = tail_pinned;
+        if (int rc = make_tail()) return rc;
+      }
+    }
     // the chunk that holds the last column coming from the host also takes every column behind it (they are already
     // in HBM: nothing to wait for, and each extra absorb launch is a round trip of the 200 B sponge state per row)
     nc = col0 + chunk >= ncols ? W - col0 : chunk;
@@ -1615,6 +1967,10 @@ int p2gpu_prove(p2gpu_circuit *c, const uint64_t *wires, const uint64_t *pis, ui
                 size_t *proof_len, p2gpu_timings *tm) try {
   if (!c || !wires || !proof_out || !proof_len) return P2GPU_E_ARG;
   if (c->device < 0) { set_err("this is a verifier-only handle (p2gpu_verifier_create): no prover state"); return P2GPU_E_ARG; }
+  if (!c->group.empty())
+    return group_prove(c, proof_out, proof_len, tm, [&](p2gpu_circuit *m, int, uint8_t *po, size_t *pl, p2gpu_timings *t) {
+      return prove_host(m, wires, m->W, nullptr, 0, pis, n_pi, po, pl, t);
+    });
   return prove_host(c, wires, c->W, nullptr, 0, pis, n_pi, proof_out, proof_len, tm);
 } P2GPU_CATCH
 
@@ -1626,6 +1982,10 @@ int p2gpu_prove_sparse(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, 
     set_err("p2gpu_prove_sparse: %u dense columns of %u wires, row %u of %zu%s", ncols, c->W, row, c->n, (ncols < c->W && !tail) ? ", no tail values" : "");
     return P2GPU_E_ARG;
   }
+  if (!c->group.empty())
+    return group_prove(c, proof_out, proof_len, tm, [&](p2gpu_circuit *m, int, uint8_t *po, size_t *pl, p2gpu_timings *t) {
+      return prove_host(m, wires, ncols, tail, row, pis, n_pi, po, pl, t);
+    });
   return prove_host(c, wires, ncols, tail, row, pis, n_pi, proof_out, proof_len, tm);
 } P2GPU_CATCH
 

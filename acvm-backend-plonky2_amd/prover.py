@@ -125,6 +125,17 @@ def _u64(a):
     return a
 
 
+def init(devices=(0,)):
+    """``p2gpu_init``: the HIP devices this process drives.  One id: one process per GPU.  Several ids: every
+    ``CircuitData`` made afterwards is a device group and each ``prove`` is ONE proof coset-sharded over those GPUs from
+    this single process (peer-to-peer exchanges between the ranks' streams, one host thread per rank inside the call) --
+    the shape the reference's one ``circuit_data.prove`` call site (prove_action.rs:96) can drive.  The number of ids
+    must divide the 8 LDE cosets; an id may repeat (ranks sharing a GPU: the functional test of this path on one GPU)."""
+    lib = load_library()
+    devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+    _check(lib.p2gpu_init(devs, len(devices)))
+
+
 def device_info():
     lib = load_library()
     name = ctypes.create_string_buffer(256)

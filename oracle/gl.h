@@ -31,12 +31,17 @@ typedef unsigned __int128 u128;
 
 static inline gl_t gl_canon(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
 
+/* (branch-free forms: the operands are random field elements, a data-dependent branch mispredicts every other call --
+ * that, not the multiplier, was most of an oracle butterfly's 20 ns) */
 static inline gl_t gl_add(gl_t a, gl_t b) {
   uint64_t s = a + b;
-  if (s < a || s >= GL_P) s -= GL_P;
-  return s;
+  uint64_t over = (uint64_t)(s < a) | (uint64_t)(s >= GL_P);
+  return s - (GL_P & (0 - over));
 }
-static inline gl_t gl_sub(gl_t a, gl_t b) { return a >= b ? a - b : a - b + GL_P; }
+static inline gl_t gl_sub(gl_t a, gl_t b) {
+  uint64_t d = a - b;
+  return d + (GL_P & (0 - (uint64_t)(a < b)));
+}
 static inline gl_t gl_neg(gl_t a) { return a ? GL_P - a : 0; }
 
 /* x mod p for a 128-bit x, using 2^64 = 2^32 - 1 and 2^96 = -1 (mod p). */
@@ -44,10 +49,10 @@ static inline gl_t gl_reduce128(u128 x) {
   uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
   uint64_t hh = hi >> 32, hl = hi & GL_EPS;
   uint64_t t0 = lo - hh;
-  if (lo < hh) t0 -= GL_EPS;
+  t0 -= GL_EPS & (0 - (uint64_t)(lo < hh));
   uint64_t t1 = hl * GL_EPS;
   uint64_t t2 = t0 + t1;
-  if (t2 < t1) t2 += GL_EPS;
+  t2 += GL_EPS & (0 - (uint64_t)(t2 < t1));
   return gl_canon(t2);
 }
 static inline gl_t gl_mul(gl_t a, gl_t b) { return gl_reduce128((u128)a * b); }

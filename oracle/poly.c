@@ -2,6 +2,11 @@
 #include "poly.h"
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <stdio.h>
+#include <omp.h>
+static int orc_trace(void) { static int v = -1; if (v < 0) { const char *e = getenv("ORC_TRACE"); v = e && *e == '1'; } return v; }
+#define TR(label) do { if (orc_trace()) { double t_ = omp_get_wtime(); fprintf(stderr, "[oracle] %s %.3f s\n", label, t_ - tr0_); tr0_ = t_; } } while (0)
 
 /* root tables shared by the threads of a batch: at most one per (size, root) pair is ever built; a handful
  * of pairs exist per proof (forward / inverse at d and d + rate_bits, the FRI sizes) */
@@ -15,10 +20,18 @@ static const gl_t *twiddles(unsigned lg, gl_t root) {
     for (int i = 0; i < g_tw_n && !found; i++)
       if (g_tw[i].lg == lg && g_tw[i].root == root) found = g_tw[i].tw;
     if (!found) {
+      /* per layer s (butterfly span m = 2^s, half = m / 2) the twiddles root^(j n/m), j < half, CONTIGUOUS at offset
+       * half - 1: the flat table root^i read with stride n/m maps a whole layer onto one L1 set */
       size_t n = (size_t)1 << lg;
-      gl_t *tw = (gl_t *)malloc(sizeof(gl_t) * (n / 2 + 1));
-      tw[0] = 1;
-      for (size_t i = 1; i < n / 2; i++) tw[i] = gl_mul(tw[i - 1], root);
+      gl_t *flat = (gl_t *)malloc(sizeof(gl_t) * (n / 2 + 1));
+      flat[0] = 1;
+      for (size_t i = 1; i < n / 2; i++) flat[i] = gl_mul(flat[i - 1], root);
+      gl_t *tw = (gl_t *)malloc(sizeof(gl_t) * (n + 1));
+      for (unsigned s2 = 1; s2 <= lg; s2++) {
+        size_t half = (size_t)1 << (s2 - 1), stride = n >> s2;
+        for (size_t j = 0; j < half; j++) tw[half - 1 + j] = flat[j * stride];
+      }
+      free(flat);
       if (g_tw_n == TW_CACHE) { /* full: drop the oldest entry (never hit by the tests; no reader holds it across calls
                                    of a different size) */
         free(g_tw[0].tw);
@@ -47,12 +60,30 @@ static void ntt_root(gl_t *a, unsigned lg, gl_t root) {
   }
   /* twiddle table w^i, i < n/2 (cached per (lg, root): every column of a batch asks for the same one) */
   const gl_t *tw = twiddles(lg, root);
-  for (unsigned s = 1; s <= lg; s++) {
-    size_t m = (size_t)1 << s, half = m >> 1, stride = n / m;
+  /* the layers whose butterflies stay inside a 2^14-element block (128 KB: L2) run block by block, the rest as full
+   * passes: the same butterflies in another order (they are independent within a layer), a third of the DRAM passes */
+  const unsigned B = lg < 14 ? lg : 14;
+  for (size_t k0 = 0; k0 < n; k0 += (size_t)1 << B) {
+    for (unsigned s = 1; s <= B; s++) {
+      size_t m = (size_t)1 << s, half = m >> 1;
+      const gl_t *tws = tw + (half - 1);
+      for (size_t k = k0; k < k0 + ((size_t)1 << B); k += m) {
+        for (size_t j = 0; j < half; j++) {
+          gl_t u = a[k + j];
+          gl_t v = gl_mul(a[k + j + half], tws[j]);
+          a[k + j] = gl_add(u, v);
+          a[k + j + half] = gl_sub(u, v);
+        }
+      }
+    }
+  }
+  for (unsigned s = B + 1; s <= lg; s++) {
+    size_t m = (size_t)1 << s, half = m >> 1;
+    const gl_t *tws = tw + (half - 1);
     for (size_t k = 0; k < n; k += m) {
       for (size_t j = 0; j < half; j++) {
         gl_t u = a[k + j];
-        gl_t v = gl_mul(a[k + j + half], tw[j * stride]);
+        gl_t v = gl_mul(a[k + j + half], tws[j]);
         a[k + j] = gl_add(u, v);
         a[k + j + half] = gl_sub(u, v);
       }
@@ -89,6 +120,18 @@ void coset_intt(gl_t *a, unsigned lg, gl_t shift) {
 }
 
 /* ------------------------------------------------------------------------ */
+/* Large buffers (the LDE of a batch is gigabytes) on transparent huge pages where the host allows it ("madvise" mode):
+ * with 4 KB pages the first touch of ~4 GB per proof is a million page faults taken by every OpenMP thread at once, and
+ * on a 128-core host that -- not arithmetic -- was most of the oracle's wall time. */
+void *big_malloc(size_t bytes) {
+  if (bytes < ((size_t)4 << 20)) return malloc(bytes);
+  void *p = NULL;
+  if (posix_memalign(&p, (size_t)2 << 20, (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1))) return NULL;
+#ifdef MADV_HUGEPAGE
+  (void)madvise(p, bytes, MADV_HUGEPAGE);
+#endif
+  return p;
+}
 static unsigned log2sz(size_t n) {
   unsigned l = 0;
   while (((size_t)1 << l) < n) l++;
@@ -102,12 +145,12 @@ void merkle_build(merkle_t *t, const gl_t *leaves, size_t n_leaves, size_t leaf_
   t->leaf_len = leaf_len;
   t->n_levels = lg - cap_h + 1;
   t->levels = (digest_t **)malloc(sizeof(digest_t *) * t->n_levels);
-  t->levels[0] = (digest_t *)malloc(sizeof(digest_t) * n_leaves);
+  t->levels[0] = (digest_t *)big_malloc(sizeof(digest_t) * n_leaves);
 #pragma omp parallel for schedule(static)
   for (size_t i = 0; i < n_leaves; i++) t->levels[0][i] = kh_hash_or_noop(leaves + i * leaf_len, leaf_len);
   for (unsigned l = 1; l < t->n_levels; l++) {
     size_t cnt = n_leaves >> l;
-    t->levels[l] = (digest_t *)malloc(sizeof(digest_t) * cnt);
+    t->levels[l] = (digest_t *)big_malloc(sizeof(digest_t) * cnt);
     const digest_t *prev = t->levels[l - 1];
     digest_t *cur = t->levels[l];
 #pragma omp parallel for schedule(static)
@@ -144,14 +187,15 @@ int merkle_verify(const gl_t *leaf, size_t leaf_len, size_t idx, const digest_t 
 static void batch_commit(batch_t *b, unsigned cap_h) {
   size_t n = (size_t)1 << b->d, N = n << b->rate_bits, nc = b->ncols;
   unsigned lgN = b->d + b->rate_bits;
-  b->leaves = (gl_t *)malloc(sizeof(gl_t) * N * nc);
+  double tr0_ = omp_get_wtime();
+  b->leaves = (gl_t *)big_malloc(sizeof(gl_t) * N * nc);
   /* column-major LDE in leaf (bit-reversed) order first, then a blocked transpose: writing leaves[bitrev(i)][c]
    * straight from the column loop makes every store a different cache line, shared with seven other threads'
    * columns -- on 128 threads that was 9.6 of the 12.5 s of a 2^20-row proof */
-  gl_t *cm = (gl_t *)malloc(sizeof(gl_t) * N * nc);
+  gl_t *cm = (gl_t *)big_malloc(sizeof(gl_t) * N * nc);
 #pragma omp parallel
   {
-    gl_t *tmp = (gl_t *)malloc(sizeof(gl_t) * N);
+    gl_t *tmp = (gl_t *)big_malloc(sizeof(gl_t) * N);
 #pragma omp for schedule(dynamic, 1)
     for (size_t c = 0; c < nc; c++) {
       /* lde: zero-pad to N, coset_fft with shift = MULTIPLICATIVE_GROUP_GENERATOR */
@@ -164,6 +208,7 @@ static void batch_commit(batch_t *b, unsigned cap_h) {
     }
     free(tmp);
   }
+  TR("lde columns");
   /* transpose to leaf-major rows */
   {
     const size_t RB = 256;
@@ -177,14 +222,16 @@ static void batch_commit(batch_t *b, unsigned cap_h) {
     }
   }
   free(cm);
+  TR("transpose");
   merkle_build(&b->tree, b->leaves, N, nc, cap_h);
+  TR("merkle");
 }
 void batch_from_values(batch_t *b, const gl_t *vals, size_t ncols, unsigned d, unsigned rate_bits, unsigned cap_h) {
   size_t n = (size_t)1 << d;
   b->ncols = ncols;
   b->d = d;
   b->rate_bits = rate_bits;
-  b->coeffs = (gl_t *)malloc(sizeof(gl_t) * n * ncols);
+  b->coeffs = (gl_t *)big_malloc(sizeof(gl_t) * n * ncols);
   memcpy(b->coeffs, vals, sizeof(gl_t) * n * ncols);
 #pragma omp parallel for schedule(dynamic, 1)
   for (size_t c = 0; c < ncols; c++) intt(b->coeffs + c * n, d);
@@ -195,7 +242,7 @@ void batch_from_coeffs(batch_t *b, const gl_t *coeffs, size_t ncols, unsigned d,
   b->ncols = ncols;
   b->d = d;
   b->rate_bits = rate_bits;
-  b->coeffs = (gl_t *)malloc(sizeof(gl_t) * n * ncols);
+  b->coeffs = (gl_t *)big_malloc(sizeof(gl_t) * n * ncols);
   memcpy(b->coeffs, coeffs, sizeof(gl_t) * n * ncols);
   batch_commit(b, cap_h);
 }

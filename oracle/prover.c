@@ -193,7 +193,7 @@ int orc_prove(const orc_circuit *oc, const uint64_t *wires, const uint64_t *pis,
   tr->t_wires = t1 - t0;
 
   /* 3. partial products and Z (C.5) */
-  gl_t *zp = (gl_t *)malloc(sizeof(gl_t) * nzp * n);
+  gl_t *zp = (gl_t *)big_malloc(sizeof(gl_t) * nzp * n);
   {
     gl_t *sub = (gl_t *)malloc(sizeof(gl_t) * n);
     gl_t w = gl_root_of_unity(d);

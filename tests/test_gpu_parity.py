@@ -755,3 +755,52 @@ def test_poseidon_hasher_full_size_and_sharded_exercise(pkg, orc, gpu):
     cd.set("shard_exercise", 1)
     assert cd.prove(wires).to_bytes() == proof.to_bytes()
     cd.close()
+
+
+# ---- one process, several devices: the device group behind p2gpu_init(ids, n > 1) ----------------------------------------
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_single_process_device_group(pkg, orc, gpu, world):
+    """p2gpu_init with several ids makes every circuit handle a device group: ONE caller thread, one proof coset-sharded
+    over the ranks, exchanges as peer copies between the ranks' streams (no RCCL, no second process) -- what a single
+    `circuit_data.prove` call site (prove_action.rs:96) can drive.  On this one-GPU box the ids repeat (the ranks share
+    the GPU): every code path of the group runs -- rank threads, rendezvous, peer all-gathers of caps / quotient
+    interpolants / PoW minima / query openings / the witness column blocks -- and the bytes equal the oracle's, through
+    every entry point, with and without public inputs, and after a failing proof."""
+    import torch
+
+    try:
+        pkg.init([0] * world)
+        for d, mix, npi in ((9, "ecdsa", 0), (12, "sha", 3)):
+            out = pkg.make_circuit(d, mix, 41, num_public_inputs=npi, pi_row_routed_only=True)
+            blob, wires = out[0], out[1]
+            pis = out[2] if npi else ()
+            want = orc.OracleCircuit(blob).prove(wires, public_inputs=pis)[0]
+            cd = pkg.CircuitData(blob)
+            assert cd.prove(wires, public_inputs=pis).to_bytes() == want                      # host witness: column blocks per rank + peer all-gather
+            wd = torch.from_numpy(wires.view(np.int64)).cuda()
+            assert cd.prove(wd, public_inputs=pis).to_bytes() == want                         # resident witness
+            assert cd.prove_routed(np.ascontiguousarray(wires[:80]), public_inputs=pis).to_bytes() == want
+            wm = wires.reshape(cd.num_wires, -1)
+            nz = (wm != 0).sum(axis=1)
+            ncols = int(np.max(np.nonzero(nz > 1)[0])) + 1 if (nz > 1).any() else 0
+            if ncols < cd.num_wires and not wm[ncols:, 1:].any():
+                sp = cd.prove_sparse(np.ascontiguousarray(wm[:ncols]).reshape(-1), ncols, 0, public_inputs=pis, tail=np.ascontiguousarray(wm[ncols:, 0]))
+                assert sp.to_bytes() == want
+            cd.verify(want)
+            # an unsatisfied witness fails on every rank at the same point; the group is usable afterwards
+            bad = wires.copy()
+            bad[0, 1] = (int(bad[0, 1]) + 1) % P
+            with pytest.raises(pkg.P2GpuError) as e:
+                cd.prove(bad, public_inputs=pis)
+            assert e.value.code == -5
+            assert cd.prove(wires, public_inputs=pis).to_bytes() == want
+            with pytest.raises(pkg.P2GpuError):
+                cd.set_shard(0, 1)       # the sharding of a group is fixed
+            cd.close()
+    finally:
+        pkg.init([0])
+    # back to one device: ordinary handles again
+    blob, wires = pkg.make_circuit(8, "arith", 3)
+    cd = pkg.CircuitData(blob)
+    assert cd.prove(wires).to_bytes() == orc.OracleCircuit(blob).prove(wires)[0]
+    cd.close()

@@ -160,6 +160,10 @@ struct RcclApi {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool ok = false;
 };
@@ -176,6 +180,10 @@ const RcclApi &rccl() {
       api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
       api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
       api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+      api.Send = (decltype(api.Send))dlsym(h, "ncclSend");
+      api.Recv = (decltype(api.Recv))dlsym(h, "ncclRecv");
+      api.GroupStart = (decltype(api.GroupStart))dlsym(h, "ncclGroupStart");
+      api.GroupEnd = (decltype(api.GroupEnd))dlsym(h, "ncclGroupEnd");
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
       api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
     }
@@ -268,7 +276,29 @@ int peer_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size_
 int shard_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size_t bytes) {
   if (c->peer) return peer_allgather(c, send_dev, recv_dev, bytes);
   if (c->rccl_comm) {
-    RCCL_TRY(rccl().AllGather(send_dev, recv_dev, bytes, ncclUint8, (ncclComm_t)c->rccl_comm, c->stream));
+    const RcclApi &r = rccl();
+    // Large payloads (the witness column blocks: 31 MB per rank at 2^20 rows, the quotient interpolants) go as one
+    // grouped send / receive per peer -- on xGMI's point-to-point links all seven transfers of a rank run at once,
+    // where a ring all-gather is bound by one link; the small ones (caps, PoW minima, query rows)
+    // stay with ncclAllGather's latency-optimised protocols.  P2GPU_RCCL_P2P_BYTES moves the threshold (0: never).
+    static const size_t p2p_min = [] {
+      const char *e = getenv("P2GPU_RCCL_P2P_BYTES");
+      return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 20);
+    }();
+    if (p2p_min && bytes >= p2p_min && r.Send && r.Recv && r.GroupStart && r.GroupEnd) {
+      const int world = c->shard_world, q = c->shard_rank;
+      uint8_t *mine = (uint8_t *)recv_dev + (size_t)q * bytes;
+      if ((const void *)mine != send_dev) HIP_TRY(hipMemcpyAsync(mine, send_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
+      RCCL_TRY(r.GroupStart());
+      for (int p = 0; p < world; p++) {
+        if (p == q) continue;
+        RCCL_TRY(r.Send(send_dev, bytes, ncclUint8, p, (ncclComm_t)c->rccl_comm, c->stream));
+        RCCL_TRY(r.Recv((uint8_t *)recv_dev + (size_t)p * bytes, bytes, ncclUint8, p, (ncclComm_t)c->rccl_comm, c->stream));
+      }
+      RCCL_TRY(r.GroupEnd());
+      return 0;
+    }
+    RCCL_TRY(r.AllGather(send_dev, recv_dev, bytes, ncclUint8, (ncclComm_t)c->rccl_comm, c->stream));
     return 0;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -263,7 +263,7 @@ void fill_row(Builder &b, const GateDef &g, uint32_t row, gl_t *lc /* local cons
 
 extern "C" {
 
-// mix: "arith" | "sha" | "ecdsa".  Returns 0 ok.  Outputs are malloc'ed; free
+// mix: "arith" | "sha" | "ecdsa" | "grammar".  Returns 0 ok.  Outputs are malloc'ed; free
 // with p2synth_free.  wires_out is [num_wires][2^d] column-major.
 // num_pi > 0 adds what `build()` adds for public inputs: PoseidonGate rows hashing them (overwrite-mode
 // sponge, 8 per permutation) and the PublicInputGate row wired to the hash; pis_out receives the values.
@@ -312,6 +312,15 @@ int p2synth_make2(unsigned d, const char *mix, uint64_t seed, uint32_t num_pi, u
     gates.push_back(mk(G_U32_SUBTRACTION, us, 0, 0, "U32SubtractionGate { num_ops: " + S(us) + ph, 4, us * 19, 0, 0.10));
     gates.push_back(mk(G_U32_RANGE_CHECK, rcl, 0, 0, "U32RangeCheckGate { num_input_limbs: " + S(rcl) + ph, 4, rcl * 17, 0, 0.10));
     gates.push_back(mk(G_COMPARISON, 32, 16, 0, "ComparisonGate { num_bits: 32, num_chunks: 16" + ph + "<D=2>", 4, 88, 0, 0.05));
+  } else if (m == "grammar") {
+    // BASELINE configs[4] ("zk-grammar medium Noir project"; SURVEY 8(d): arith + sha mix incl. RandomAccess / memory
+    // ops): field arithmetic, bit and base-4 decompositions, and memory reads -- the translator turns every ACIR
+    // MemoryOp read into a RandomAccessGate lookup (circuit_translation/memory_translator.rs:118-122)
+    gates.push_back(mk(G_ARITHMETIC, 20, 0, 0, "ArithmeticGate { num_ops: 20 }", 3, 20, 2, 0.55));
+    gates.push_back(mk(G_BASE_SUM, 2, 32, 0, "BaseSumGate { num_limbs: 32 } + Base: 2", 2, 33, 0, 0.20));
+    gates.push_back(mk(G_BASE_SUM, 4, 16, 0, "BaseSumGate { num_limbs: 16 } + Base: 4", 4, 17, 0, 0.05));
+    gates.push_back(mk(G_RANDOM_ACCESS, 4, 4, 2,
+                       "RandomAccessGate { bits: 4, num_copies: 4, num_extra_constants: 2" + ph + "<D=2>", 5, 26, 2, 0.20));
   } else {
     return -2;
   }

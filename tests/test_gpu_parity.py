@@ -108,7 +108,7 @@ def test_commit_cap_matches_oracle(pkg, orc, gpu, d, ncols):
 
 @pytest.mark.parametrize("d,mix,seed", [
     (5, "arith", 1), (5, "ecdsa", 2), (6, "sha", 3), (8, "ecdsa", 4), (9, "arith", 5),
-    (11, "sha", 6), (12, "ecdsa", 7), (13, "ecdsa", 8), (13, "arith", 9), (14, "sha", 10),
+    (11, "sha", 6), (12, "ecdsa", 7), (13, "ecdsa", 8), (13, "arith", 9), (14, "sha", 10), (7, "grammar", 12), (12, "grammar", 13),
 ])
 def test_proof_bytes_match_oracle(pkg, orc, gpu, d, mix, seed):
     blob, wires = pkg.make_circuit(d, mix, seed)
@@ -355,10 +355,11 @@ def test_error_paths(pkg, gpu):
     assert len(cd.prove(wires)) > 0
 
 
-@pytest.mark.parametrize("d,mix", [(19, "ecdsa"), (21, "arith")])
+@pytest.mark.parametrize("d,mix", [(19, "ecdsa"), (21, "arith"), (21, "grammar")])
 def test_larger_configs_are_accepted(pkg, orc, gpu, d, mix):
     """BASELINE configs[3] / configs[4] sizes on ONE GPU: 2^22 LDE rows with every gate kind,
-    2^24 LDE rows (12 + 9 layer NTT, ~55 GB resident).  Property check: the verifier accepts."""
+    2^24 LDE rows (12 + 9 layer NTT, ~55 GB resident; `grammar` = SURVEY 8(d)'s gate mix for configs[4]: arithmetic,
+    base-2 / base-4 sums and RandomAccessGate memory reads).  Property check: the verifier accepts."""
     blob, wires = pkg.make_circuit(d, mix, 2)
     cd = pkg.CircuitData(blob)
     proof = cd.prove(wires)

@@ -102,8 +102,15 @@ def step_of(kernel):
     return None
 
 
+PROFILE_TAG = ""   # "ecdsa_" when the bench runs the all-gate-kinds mix: profiles/rNN_ecdsa_* hold that workload's counters
+
+
 def newest(pattern):
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    """Newest committed profile summary of THIS workload: profiles/rNN[x]_<PROFILE_TAG><kind>.json."""
+    import re
+    kind = pattern.split("*_", 1)[1]
+    rx = re.compile(r"^r\d+[a-z]?_" + re.escape(PROFILE_TAG + kind) + "$")
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pattern)) if rx.match(os.path.basename(f)))
     return files[-1] if files else None
 
 
@@ -126,7 +133,8 @@ def mix_ceiling(kernel):
     """Ceiling of the kernel's own VALU mix in lane-instr/s (see VALU_PEAK above) and where it comes from."""
     if kernel.startswith(("hash_lde", "hash_fri", "merkle", "pow_kernel")) and "<1" not in kernel.split(",")[0]:
         return KECCAK_MIX_CEILING, "Keccak-f round = 120 v_bitop3_b32 (full rate) + 58 v_alignbit_b32 (half rate): measured as an interleaved stream, profiles/r03_ubench.txt"
-    f = newest("r*_isa_mix.json")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_mix.json")))   # static: one file for every workload
+    f = files[-1] if files else None
     if f:
         try:
             with open(f) as fh:
@@ -299,6 +307,8 @@ def main():
         assert lib.p2gpu_init(dev, 1) == 0, lib.p2gpu_last_error()
 
     d, mix = args.degree_bits, args.mix
+    global PROFILE_TAG
+    PROFILE_TAG = "ecdsa_" if (args.workload == "synth" and mix == "ecdsa") else ""
     # every rank proves its own witness of the same circuit shape (independent proofs)
     sharded = args.mode == "sharded" and world > 1
     if args.workload == "sha256":

@@ -805,3 +805,40 @@ def test_single_process_device_group(pkg, orc, gpu, world):
     cd = pkg.CircuitData(blob)
     assert cd.prove(wires).to_bytes() == orc.OracleCircuit(blob).prove(wires)[0]
     cd.close()
+
+
+# ---- FRI / commitment parameters other than the reference's (cap 2^4, 16 PoW bits) -------------------------------------
+@pytest.mark.parametrize("d,mix,cap_h,pow_bits,queries", [(8, "ecdsa", 3, 16, 28), (8, "sha", 5, 8, 10), (9, "arith", 7, 16, 28),
+                                                           (8, "ecdsa", 11, 12, 5), (10, "sha", 12, 16, 28), (9, "sha", 4, 21, 28)])
+def test_other_cap_heights_and_pow_bits(pkg, orc, gpu, d, mix, cap_h, pow_bits, queries):
+    """The pinned staging arena of a proof is sized from the circuit: 3 + n_steps trees stage 2^cap_h digests
+    each, and the PoW loop takes its staging words once however many candidate batches it grinds through (21 bits:
+    ~2^21 candidates expected, several batches).  Same circuit rebuilt with other cap heights / PoW bits / query counts
+    through p2gpu_build_blob (cap heights from rate_bits -- a coset owns whole cap subtrees -- up to rate_bits + d, where the cap
+    IS the leaf level): GPU bytes == oracle bytes, both verifiers accept."""
+    import ctypes
+    import test_build as tb
+
+    blob0 = pkg.make_circuit(d, mix, 61)[0]
+    wires = pkg.make_circuit(d, mix, 61)[1]
+    params, gates, ng, row_gate, gconst, copies = tb.decompose(blob0)
+    params.cap_height, params.proof_of_work_bits, params.num_query_rounds = cap_h, pow_bits, queries
+    fn = pkg.load_library().p2gpu_build_blob
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                   ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    blob = tb.build_with(fn, params, gates, ng, row_gate, gconst, copies)
+    h = blob[:256].view(np.uint32)
+    assert int(h[10]) == cap_h and int(h[11]) == pow_bits and int(h[12]) == queries
+    cd = pkg.CircuitData(blob)
+    oc = orc.OracleCircuit(blob)
+    want, tr = oc.prove(wires)
+    for _ in range(2):       # twice on one handle: the arena is reset, not regrown
+        got = cd.prove(wires)
+        assert got.to_bytes() == want and got.timings["pow_witness"] == tr.pow_witness
+    assert oc.verify(want)
+    cd.verify(want)
+    # the stage-level commitment operator has its own small arena
+    v = _rand((5, 1 << d), 7)
+    assert pkg.commit_values(v, 3, cap_h) == orc.commit_values(v, 3, cap_h)
+    cd.close()
+    oc.close()

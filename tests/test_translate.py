@@ -140,3 +140,19 @@ def test_range_and_xor_opcodes(pkg, orc):
         cb2.translate_circuit([("range", 0, 8), ("range", 1, 33), ("and", 0, 2, 3, 8)])
         with pytest.raises(ValueError):
             cb2.build(bad)
+
+
+def test_identical_arithmetic_operations_share_their_output(pkg):
+    """plonky2's CircuitBuilder::arithmetic keeps `base_arithmetic_results`: the same (const_0, const_1, multiplicand_0,
+    multiplicand_1, addend) returns the earlier output target instead of a new ArithmeticGate slot -- so does the restated
+    builder, otherwise gate counts, sigma and the circuit digest drift from the reference's build()."""
+    cb = pkg.translate.CircuitBuilder()
+    x, y, z = cb.add_virtual_target(), cb.add_virtual_target(), cb.add_virtual_target()
+    a = cb.mul_add(x, y, z)
+    ops_before = sum(len(r["ops"]) for r in cb.rows if r["kind"] == "arith")
+    assert cb.mul_add(x, y, z) == a                      # cached
+    assert cb.arithmetic(1, 1, x, y, z) == a
+    assert sum(len(r["ops"]) for r in cb.rows if r["kind"] == "arith") == ops_before
+    b = cb.mul_add(y, x, z)                              # operand order is part of the key, as upstream
+    assert b != a and sum(len(r["ops"]) for r in cb.rows if r["kind"] == "arith") == ops_before + 1
+    assert cb.mul(x, y) != a and cb.mul(x, y) == cb.mul(x, y)

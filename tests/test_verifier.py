@@ -220,6 +220,22 @@ def test_poseidon_hasher_oracle_prover_vs_product_verifier(pkg, orc, d, mix, npi
     ock, vdk, _, _ = make(pkg, orc, d, mix, 9, npi, hasher=0)
     with pytest.raises(pkg.P2GpuError):
         vdk.verify(proof)
+    # Poseidon digests are field elements: w and w + p hash alike, so a cap word re-encoded as w + p (when that still
+    # fits 64 bits) would be a second byte string for the same proof -- only the canonical encoding is accepted, in the
+    # proof (first cap entry = first bytes) and in the verifier key
+    w = int.from_bytes(proof[:8], "little")
+    small = [i for i in range(0, 4 * 16 * 3 * 8, 8) if int.from_bytes(proof[i:i + 8], "little") < (1 << 32) - 1]
+    if small:
+        i = small[0]
+        enc = bytearray(proof)
+        enc[i:i + 8] = (int.from_bytes(proof[i:i + 8], "little") + P).to_bytes(8, "little")
+        with pytest.raises(pkg.P2GpuError):
+            vd.verify(bytes(enc))
+    vk = bytearray(vd.to_bytes())
+    capoff = 256 + 48 * int(np.frombuffer(bytes(vk[:256]), dtype=np.uint32)[23])
+    vk[capoff:capoff + 8] = ((1 << 64) - 1).to_bytes(8, "little")      # >= p: not a field element
+    with pytest.raises(pkg.P2GpuError):
+        pkg.VerifierCircuitData(bytes(vk))
 
 
 @pytest.mark.parametrize("d,mix,seed,npi,nw,hasher", [

@@ -13,15 +13,20 @@
 //     LDE row i = 8k + r is output k of coset r.  No transpose, no bit-reversal
 //     pass and no zero-padded 8n-point FFT ever touches HBM.
 // A transform of 2^d points is split into passes of <= 12 layers; a pass stages a
-// 2^12-element tile (32 KB + padding) in LDS and reads/writes HBM in runs of
+// 2^12-element tile (32 KB, XOR-swizzled: pidx() below) in LDS and reads/writes HBM in runs of
 // >= 128 contiguous bytes.  Inside a pass the layers are done in rounds of up to
-// four: a lane holds 16 elements in registers, multiplies them by 15 per-group
+// three: a lane holds 8 elements in registers, multiplies them by 7 per-group
 // twiddles (one coalesced load each from a table packed per round -- no index
-// arithmetic, no scattered root-table gathers) and then runs a 16-point DFT whose
-// internal twiddles are powers of w_16 = 2^12, i.e. shifts (2 is a 192nd
-// root of unity in Goldilocks): 15 general modmuls per 16 elements per four
-// layers instead of 32.  This kernel is integer-ALU bound on gfx950 (a 64x64
-// modmul is ~29 VALU); the HBM traffic equals the algorithmic bytes.  No MFMA.
+// arithmetic, no scattered root-table gathers) and then runs an 8-point DFT whose
+// internal twiddles are powers of w_8 = 2^24, i.e. shifts (2 is a 192nd
+// root of unity in Goldilocks): 7 general modmuls per 8 elements per three
+// layers instead of 12.  This kernel is VALU-issue bound on gfx950, in the HALF-rate
+// instruction class (carry chains, v_mad_u64_u32: 4.2 cycles per wave64 instruction,
+// profiles/r03_ubench.txt): 0.73-0.82 of the 39.5 T lane-instr/s its mix allows.
+// HBM traffic of a 2^17-point LDE: 25n * 8 B per dense column against 9n * 8 B
+// algorithmic (the intermediate between the 12-layer and the 5-layer pass goes out
+// and back: a 1 MB column-coset does not fit a CU's LDS) -- 2.5 TB/s while the
+// kernel runs, not its limiter.  No MFMA.
 #include "internal.hpp"
 #include "glphi.hpp"
 #include <algorithm>

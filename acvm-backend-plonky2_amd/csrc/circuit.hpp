@@ -267,6 +267,8 @@ struct CircuitState {
   uint64_t pow_hint = UINT64_MAX;
   int profile = 0;
   int self_check = 1;
+  int blocking_sync = 0;             // knob: sleep (blocking event) instead of spinning at the transcript sync points
+  hipEvent_t sync_event = nullptr;
   std::map<std::string, KernelStat> kstats;
   std::vector<PendingEv> pending;
   std::vector<hipEvent_t> event_pool;

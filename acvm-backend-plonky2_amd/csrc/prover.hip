@@ -358,6 +358,22 @@ size_t tail_nodes() {
 // device copy of the Poseidon round constants when the circuit's hasher is PoseidonHash, nullptr for Keccak
 const gl_t *hprc(const p2gpu_circuit *c) { return c->hasher == 1 ? c->d_prc.p : nullptr; }
 
+// The transcript sync points of a proof.  Default: hipStreamSynchronize, which spins on the host (lowest latency: the
+// eleven round trips of a lone proof).  Knob "blocking_sync" = 1: record an event created with hipEventBlockingSync and
+// sleep on it instead -- a woken thread costs ~10-30 us more per round trip, but a process with several proofs in
+// flight no longer burns one CPU per host thread while the GPU works (4 spinning threads per GPU are 32 CPUs on an
+// 8-GPU node: more than the 16-CPU cgroup quota of the MI355X boxes, where the spinning would throttle the ranks).
+int wait_stream(p2gpu_circuit *c) {
+  if (!c->blocking_sync) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  if (!c->sync_event) HIP_TRY(hipEventCreateWithFlags(&c->sync_event, hipEventBlockingSync | hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(c->sync_event, c->stream));
+  HIP_TRY(hipEventSynchronize(c->sync_event));
+  return 0;
+}
+
 int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
   const uint32_t C = c->C, CL = b.ncl;
   size_t m = m0;
@@ -380,7 +396,7 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
     HIP_TRY(hipMemcpyAsync(raw, b.dig.p + b.level_off.back(), C * cap_per * sizeof(dig_t), hipMemcpyDeviceToHost,
                            c->stream));
     g_hp.mark("enq(cap)");
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc_ = wait_stream(c)) return rc_;
     g_hp.mark("WAIT(cap)");
   } else {
     // coset r owns whole cap subtrees: exchange the CL * cap_per local roots (the path's only
@@ -390,7 +406,7 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
     dig_t *all = c->pin.take<dig_t>((size_t)c->shard_world * CL * cap_per);
     if (!all) return pin_exhausted();
     HIP_TRY(hipMemcpyAsync(all, c->xchg_recv.p, (size_t)c->shard_world * CL * cap_per * sizeof(dig_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc_ = wait_stream(c)) return rc_;
     shard_assemble_cap(c->shard_world, c->rate_bits, cap_per, all, b.cap);
     return 0;
   }
@@ -712,7 +728,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
       h_val = hv;
     }
     g_hp.mark("enq(openings)");
-    HIP_TRY(hipStreamSynchronize(st));
+    if (int rc_ = wait_stream(c)) return rc_;
     g_hp.mark("WAIT(openings)");
     // Which wires a circuit leaves unused does not change from proof to proof.  A handle whose witness turned
     // out (almost) fully dense stops looking: the class pass over the witness and the fill launches cost ~0.1 ms
@@ -812,7 +828,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     if (!raw) return pin_exhausted();
     HIP_TRY(hipMemcpyAsync(raw, c->fri_coef[c->n_steps].p, 16 * n_final, hipMemcpyDeviceToHost, st));
     g_hp.mark("enq(final_poly)");
-    HIP_TRY(hipStreamSynchronize(st));
+    if (int rc_ = wait_stream(c)) return rc_;
     g_hp.mark("WAIT(final_poly)");
     for (size_t j = 0; j < n_final; j++) {
       size_t p = brev((uint32_t)j, ds);
@@ -848,14 +864,14 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
         if (int rc = shard_allgather(c, c->pow_result.p, c->xchg_recv.p, 8)) return rc;
         HIP_TRY(hipMemcpyAsync(allw, c->xchg_recv.p, 8 * (size_t)c->shard_world, hipMemcpyDeviceToHost, st));
         g_hp.mark("enq(pow)");
-        HIP_TRY(hipStreamSynchronize(st));
+        if (int rc_ = wait_stream(c)) return rc_;
         g_hp.mark("WAIT(pow)");
         pw[1] = ~0ull;
         for (int q = 0; q < c->shard_world; q++) pw[1] = std::min(pw[1], allw[q]);
       } else {
         HIP_TRY(hipMemcpyAsync(&pw[1], c->pow_result.p, 8, hipMemcpyDeviceToHost, st));
         g_hp.mark("enq(pow)");
-        HIP_TRY(hipStreamSynchronize(st));
+        if (int rc_ = wait_stream(c)) return rc_;
         g_hp.mark("WAIT(pow)");
       }
       const unsigned long long res = pw[1];
@@ -962,7 +978,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   if (!sharded(c)) {
     HIP_TRY(hipMemcpyAsync(gathered, c->gather_out.p, ptrs.size() * 8, hipMemcpyDeviceToHost, st));
     g_hp.mark("enq(gather)");
-    HIP_TRY(hipStreamSynchronize(st));
+    if (int rc_ = wait_stream(c)) return rc_;
     g_hp.mark("WAIT(gather)");
   } else {
     // each rank gathered the queries that fall into its cosets: exchange and pick every query
@@ -970,7 +986,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     if (int rc = shard_allgather(c, c->gather_out.p, c->xchg_recv.p, ptrs.size() * 8)) return rc;
     std::vector<gl_t> all((size_t)world * ptrs.size());
     HIP_TRY(hipMemcpyAsync(all.data(), c->xchg_recv.p, all.size() * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (int rc_ = wait_stream(c)) return rc_;
     for (size_t qi = 0; qi < qidx.size(); qi++) {
       const uint32_t owner = brev((uint32_t)(qidx[qi] >> d), lgC) % (uint32_t)world;
       memcpy(&gathered[qi * per_query], &all[(size_t)owner * ptrs.size() + qi * per_query], per_query * 8);
@@ -1056,6 +1072,8 @@ void circuit_release(p2gpu_circuit *c) {
   c->wire_clean.release();
   c->wire_scalar.release(); c->sparse_coeffs.release(); c->sparse_lde.release(); c->sparse_partial.release();
   c->pin.release();
+  if (c->sync_event) (void)hipEventDestroy(c->sync_event);
+  c->sync_event = nullptr;
   if (c->tail_stage) (void)hipHostFree(c->tail_stage);
   c->tail_stage = nullptr;
   c->pow_result.release(); c->gather_ptrs.release(); c->gather_out.release(); c->xchg_recv.release();
@@ -1584,6 +1602,7 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
   if (k == "pow_hint") c->pow_hint = value;
   else if (k == "self_check") c->self_check = (int)value;
   else if (k == "shard_exercise") c->shard_exercise = (int)value;
+  else if (k == "blocking_sync") c->blocking_sync = (int)value;
   else if (k == "virtual_columns") {
     c->virtual_columns = (int)value;
     // a clean mark set while the knob was on vouches for the coefficients only (the LDE was never written): forget them

@@ -264,6 +264,10 @@ def main():
                     help="comma-separated HIP device ids driven by THIS ONE process as a device group (p2gpu_init with several "
                          "ids): every proof is coset-sharded over them, exchanges are peer copies between the ranks' streams. "
                          "Not combined with --gpus > 1.  An id may repeat (ranks sharing a GPU: functional check on a one-GPU box)")
+    ap.add_argument("--blocking-sync", choices=["auto", "0", "1"], default="auto",
+                    help="knob blocking_sync of every handle: 1 = the host threads sleep at the transcript sync points instead of "
+                         "spinning in hipStreamSynchronize.  auto: 1 when ranks x proofs in flight exceed half the CPUs this process "
+                         "may use (cgroup quota), e.g. 8 ranks x 4 threads on a 16-CPU quota; 0 otherwise (lowest latency)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-single-thread-bits", type=int, default=15,
                     help="degree bits of the one-thread oracle sample (0 = skip the one-thread leg)")
@@ -338,6 +342,10 @@ def main():
         pis = made[2] if args.public_inputs else ()
     S = 1 if sharded else max(1, min(args.in_flight, args.steps, 1 if d >= 21 else (2 if d == 20 else 8)))
     cds = [pkg.CircuitData(blob) for _ in range(S)]
+    blocking = (world * S * 2 > effective_cores()) if args.blocking_sync == "auto" else args.blocking_sync == "1"
+    if blocking:
+        for cd_ in cds:
+            cd_.set("blocking_sync", 1)
     if os.environ.get("P2GPU_BENCH_NO_SELF_CHECK"):  # kernel-timing experiments with deliberately wrong kernels (scratch/) only
         for cd_ in cds:
             cd_.set("self_check", 0)
@@ -594,6 +602,7 @@ def main():
             "single_proof": {"in_flight": 1, "ms_per_proof": single_ms, "proofs_per_sec": (1 if sharded else world) * 1e3 / single_ms,
                              "note": "one proof on the GPU at a time (the round-1 headline configuration)"},
             "in_flight_per_gpu": S,
+            "blocking_sync": bool(blocking),
             "host_witness": host,
             "pipelined": pipe,
             "phase_ms": {k: v / args.steps for k, v in sorted(phase.items())},

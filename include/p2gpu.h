@@ -208,7 +208,9 @@ int p2gpu_verify_compressed(const p2gpu_circuit *c, const uint8_t *cproof, size_
  * are zero in every row -- the wires no gate of the circuit uses -- and stores zeros instead of running their
  * inverse transform and LDE; the proof bytes do not depend on it), "virtual_columns" (0/1, default 1: structured
  * wire columns that only the leaf hash and the query gather read are never stored -- both recompute them as scalar x
- * LDE(unit column); the proof bytes do not depend on it) */
+ * LDE(unit column); the proof bytes do not depend on it), "blocking_sync" (0/1, default 0: at the eleven transcript sync
+ * points of a proof the calling thread spins in hipStreamSynchronize -- lowest latency; 1 = it sleeps on a blocking event,
+ * ~10-30 us later per sync but without burning a CPU per proof in flight: for hosts with fewer CPUs than proving threads) */
 int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value);
 /* statistics accumulated while "profile" = 1, one entry per kernel symbol:
  * names[64*i] (NUL-terminated), total milliseconds, total algorithmic bytes,

@@ -106,6 +106,35 @@ __device__ __forceinline__ uint64_t krot(uint64_t x) {
 #include "keccak_sched.inc"
 #endif
 
+#ifndef P2_KECCAK_FIXED
+#define P2_KECCAK_FIXED 1  // leaf-hash kernels: the explicit-register permutation of keccak_fixed.inc (gen_keccak_fixed.py)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && P2_KECCAK_FIXED
+// Keccak-f with the sponge state in FIXED physical registers v[P2_KF_BASE ...) for the whole life of a kernel: the 24 rounds
+// unrolled, registers assigned so that no v_bitop3_b32 has its three sources in one VGPR bank, no compiler-inserted wait
+// states (gen_keccak_fixed.py; 11.3 vs 10.3 Gperm/s for the compiler-allocated ordered stream, 9.7 for hipcc's own code).
+// A kernel that uses these macros carries P2_KF_KERNEL_ATTR: hipcc then allocates below
+// P2_KF_BASE only, and lane i of the state is v[P2_KF_BASE + 2i] (low half), v[P2_KF_BASE + 2i + 1] (high half) between
+// the statements below, which are all `asm volatile` (kept in program order).
+#include "keccak_fixed.inc"
+#define P2_KF_SET(i, lo, hi)                                                                                     \
+  asm volatile("v_mov_b32 v%c2, %0\n v_mov_b32 v%c3, %1" ::"v"(lo), "v"(hi), "n"(P2_KF_BASE + 2 * (i)), "n"(P2_KF_BASE + 2 * (i) + 1))
+#define P2_KF_XOR(i, lo, hi)                                                                                     \
+  asm volatile("v_xor_b32 v%c2, v%c2, %0\n v_xor_b32 v%c3, v%c3, %1" ::"v"(lo), "v"(hi), "n"(P2_KF_BASE + 2 * (i)), "n"(P2_KF_BASE + 2 * (i) + 1))
+#define P2_KF_GET(i, lo, hi)                                                                                     \
+  asm volatile("v_mov_b32 %0, v%c2\n v_mov_b32 %1, v%c3" : "=v"(lo), "=v"(hi) : "n"(P2_KF_BASE + 2 * (i)), "n"(P2_KF_BASE + 2 * (i) + 1))
+// (on gfx950's unified register file hipcc gives a kernel TWICE the number it is asked for -- measured: 18 -> v0..v35,
+// 20 -> v0..v39, 22 -> v0..v43 -- so BASE / 2 keeps it below P2_KF_BASE; `make kf-check` verifies it on the built code)
+#define P2_KF_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(P2_KF_BASE / 2)))
+#else
+// host pass of hipcc: the kernels that use these are only parsed
+#define P2_KF_KERNEL_ATTR
+#define P2_KF_SET(i, lo, hi) ((void)(lo), (void)(hi))
+#define P2_KF_XOR(i, lo, hi) ((void)(lo), (void)(hi))
+#define P2_KF_GET(i, lo, hi) ((lo) = 0, (hi) = 0)
+#define P2_KECCAK_FIXED_PERMUTE() ((void)0)
+#endif
+
 // st[x + 5y]
 P2_HD void keccak_f1600(uint64_t st[25]) {
   const uint64_t RC[24] = {

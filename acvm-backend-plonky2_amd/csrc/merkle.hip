@@ -175,6 +175,140 @@ __global__ __launch_bounds__(256, V ? P2_LEAFV_WAVES : P2_LEAF_WAVES) void hash_
   }
 }
 
+#if P2_KECCAK_FIXED
+// ---- Keccak leaf hashing with the sponge state in fixed registers (keccak.hpp P2_KF_*) ----------------------------------
+template <int I, int N, class F>
+__device__ __forceinline__ void kf_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    kf_for<I + 1, N>(f);
+  }
+}
+__device__ __forceinline__ void kf_zero() {
+  kf_for<0, 25>([&](auto ic) { P2_KF_SET(decltype(ic)::value, 0u, 0u); });
+}
+// One sponge step: absorb the next rate block -- 17 full words, or (the last step) the ragged tail of rem < 17 words with the
+// original Keccak padding -- and permute.  ONE call site of the 34 KB permutation per kernel: two would not fit the
+// 64 KB instruction cache together.
+// words [W0, W1) of the rate block: all loads of the group first, then the XORs -- an `asm volatile` is a scheduling barrier
+// for hipcc, so a load written next to its XOR is waited for before the next one is even issued (17 dependent HBM latencies
+// per block).  G = words per group: what the compiler's share of the register file (P2_KF_BASE registers) can hold.
+template <int W0, int W1, class F>
+__device__ __forceinline__ void kf_absorb_group(uint32_t off, F get) {
+  uint64_t x[W1 - W0];
+#pragma unroll
+  for (int w = W0; w < W1; w++) x[w - W0] = get(off + w);
+  kf_for<W0, W1>([&](auto wc) {
+    constexpr int w = decltype(wc)::value;
+    const uint64_t xw = x[w - W0];  // (an asm operand may not name a captured variable)
+    const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
+    P2_KF_XOR(w, lo, hi);
+  });
+}
+template <bool SPLIT, class F>
+__device__ __forceinline__ void kf_absorb(uint32_t off, uint32_t rem, F get) {
+  if (rem >= 17) {
+    if constexpr (SPLIT) {  // virtual columns: each word may be a modular product, which needs registers of its own
+      kf_absorb_group<0, 6>(off, get);
+      kf_absorb_group<6, 12>(off, get);
+      kf_absorb_group<12, 17>(off, get);
+    } else {
+      kf_absorb_group<0, 17>(off, get);
+    }
+  } else {
+    kf_for<0, 17>([&](auto wc) {  // once per leaf: word by word
+      constexpr int w = decltype(wc)::value;
+      if ((uint32_t)w <= rem) {
+        const uint64_t xw = (uint32_t)w < rem ? get(off + w) : (uint64_t)1;  // ... | 0x01 pad
+        const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
+        P2_KF_XOR(w, lo, hi);
+      }
+    });
+    P2_KF_XOR(16, 0u, 0x80000000u);
+  }
+}
+__device__ __forceinline__ dig_t kf_digest() {
+  uint32_t l0, h0, l1, h1, l2, h2, l3, h3;
+  P2_KF_GET(0, l0, h0);
+  P2_KF_GET(1, l1, h1);
+  P2_KF_GET(2, l2, h2);
+  P2_KF_GET(3, l3, h3);
+  dig_t dg;
+  dg.w[0] = ((uint64_t)h0 << 32) | l0;
+  dg.w[1] = ((uint64_t)h1 << 32) | l1;
+  dg.w[2] = ((uint64_t)h2 << 32) | l2;
+  dg.w[3] = l3 & 0xFFu;
+  (void)h3;
+  return dg;
+}
+// same contract as hash_lde_leaves_kernel<0, V>; rows of <= 3 elements (copied, not hashed) never come here
+template <bool V>
+__global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void hash_lde_leaves_kf_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
+                                                                                   dig_t *__restrict__ dig, const VirtCols v) {
+  const size_t n = (size_t)1 << d;
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = blockIdx.y;
+  if (k >= n) return;
+  const gl_t *base = lde + (size_t)c * cols * n + k;
+  gl_t Lk = 0;
+  if constexpr (V) Lk = v.basis ? v.basis[(size_t)(v.coset_first + c * v.coset_stride) * n + k] : (gl_t)0;
+  auto get = [&](uint32_t i) -> gl_t {
+    if constexpr (V) return virt_get(v, i, Lk, base, n);
+    else return base[(size_t)i * n];
+  };
+  kf_zero();
+  for (uint32_t off = 0;; off += 17) {
+    const uint32_t rem = cols - off;
+    kf_absorb<V>(off, rem, get);
+    P2_KECCAK_FIXED_PERMUTE();
+    if (rem < 17) break;
+  }
+  dig[(size_t)c * n + k] = kf_digest();
+}
+// hash_lde_absorb_kernel with the state in fixed registers between the HBM round trips
+template <bool V>
+__global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void hash_lde_absorb_kf_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
+                                                                                   uint32_t blk0, uint32_t nblk, int first, int last,
+                                                                                   uint64_t *__restrict__ state, dig_t *__restrict__ dig, const VirtCols v) {
+  const size_t n = (size_t)1 << d;
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = blockIdx.y;
+  if (k >= n) return;
+  const gl_t *base = lde + (size_t)c * cols * n + k;
+  uint64_t *sp = state + (size_t)c * 25 * n + k;
+  gl_t Lk = 0;
+  if constexpr (V) Lk = v.basis ? v.basis[(size_t)(v.coset_first + c * v.coset_stride) * n + k] : (gl_t)0;
+  auto get = [&](uint32_t i) -> gl_t {
+    if constexpr (V) return virt_get(v, i, Lk, base, n);
+    else return base[(size_t)i * n];
+  };
+  if (first) kf_zero();
+  else
+    kf_for<0, 25>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const uint64_t x = sp[(size_t)i * n];
+      P2_KF_SET(i, (uint32_t)x, (uint32_t)(x >> 32));
+    });
+  // nblk full blocks, then (last call only) the ragged tail: cols - 17 * (blk0 + nblk) < 17 words
+  const uint32_t steps = nblk + (last ? 1u : 0u);
+  for (uint32_t b = 0; b < steps; b++) {
+    const uint32_t off = 17 * (blk0 + b);
+    kf_absorb<true>(off, b < nblk ? 17u : cols - off, get);  // (groups of 6: this kernel also holds the state pointers)
+    P2_KECCAK_FIXED_PERMUTE();
+  }
+  if (last) {
+    dig[(size_t)c * n + k] = kf_digest();
+  } else {
+    kf_for<0, 25>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      uint32_t lo, hi;  // (locals of the lambda: an asm output may not name a captured variable)
+      P2_KF_GET(i, lo, hi);
+      sp[(size_t)i * n] = ((uint64_t)hi << 32) | lo;
+    });
+  }
+}
+#endif
+
 // Leaf hashing for a witness that arrives in column chunks (p2gpu_prove): a Keccak sponge absorbs
 // 17 columns per permutation, in column order, so the rate blocks of the columns already on the
 // device can be absorbed while later columns are still crossing PCIe.  The 25-word state of every
@@ -289,15 +423,30 @@ void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d,
                      const VirtCols *virt) {
   size_t n = (size_t)1 << d;
   uint32_t threads = n >= 256 ? 256 : 64;
+#if P2_KECCAK_FIXED
+  // Keccak, a hashed leaf (more than 3 elements) and full 256-lane blocks: the fixed-register sponge (profile names = the
+  // symbols rocprofv3 shows)
+  const bool kf = !prc && cols * 8 > 25 && n >= 256;
+#else
+  const bool kf = false;
+#endif
   if (virt && virt->cls && virt->first < cols) {  // the wires of a proof with unmaterialised columns (same digests)
-    ProfScope ps(prc ? "hash_lde_leaves_kernel<1, true>" : "hash_lde_leaves_kernel<0, true>", (8.0 * cols + 32.0) * cosets * (double)n);
+    ProfScope ps(prc ? "hash_lde_leaves_kernel<1, true>" : (kf ? "hash_lde_leaves_kf_kernel<true>" : "hash_lde_leaves_kernel<0, true>"),
+                 (8.0 * cols + 32.0) * cosets * (double)n);
     if (prc) hipLaunchKernelGGL((hash_lde_leaves_kernel<1, true>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, *virt);
+#if P2_KECCAK_FIXED
+    else if (kf) hipLaunchKernelGGL((hash_lde_leaves_kf_kernel<true>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, *virt);
+#endif
     else hipLaunchKernelGGL((hash_lde_leaves_kernel<0, true>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, *virt);
     return;
   }
   // same spelling as rocprofv3's demangled names (<0> Keccak, <1> Poseidon), so the bench line and profiles/ agree
-  ProfScope ps(prc ? "hash_lde_leaves_kernel<1, false>" : "hash_lde_leaves_kernel<0, false>", (8.0 * cols + 32.0) * cosets * (double)n);
+  ProfScope ps(prc ? "hash_lde_leaves_kernel<1, false>" : (kf ? "hash_lde_leaves_kf_kernel<false>" : "hash_lde_leaves_kernel<0, false>"),
+               (8.0 * cols + 32.0) * cosets * (double)n);
   if (prc) hipLaunchKernelGGL((hash_lde_leaves_kernel<1, false>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, VirtCols());
+#if P2_KECCAK_FIXED
+  else if (kf) hipLaunchKernelGGL((hash_lde_leaves_kf_kernel<false>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, VirtCols());
+#endif
   else hipLaunchKernelGGL((hash_lde_leaves_kernel<0, false>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, VirtCols());
 }
 void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, uint32_t blk0,
@@ -306,6 +455,17 @@ void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d,
   uint32_t threads = n >= 256 ? 256 : 64;
   ProfScope ps("hash_lde_absorb_kernel", (8.0 * 17 * nblk + (first ? 0 : 200) + (last ? 32 + 8.0 * (cols - 17 * (blk0 + nblk)) : 200)) *
                                              cosets * (double)n);
+#if P2_KECCAK_FIXED
+  if (n >= 256) {
+    if (virt && virt->cls && virt->first < cols)
+      hipLaunchKernelGGL(hash_lde_absorb_kf_kernel<true>, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols,
+                         d, blk0, nblk, first ? 1 : 0, last ? 1 : 0, state, dig, *virt);
+    else
+      hipLaunchKernelGGL(hash_lde_absorb_kf_kernel<false>, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols,
+                         d, blk0, nblk, first ? 1 : 0, last ? 1 : 0, state, dig, VirtCols());
+    return;
+  }
+#endif
   if (virt && virt->cls && virt->first < cols)
     hipLaunchKernelGGL(hash_lde_absorb_kernel<true>, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols,
                        d, blk0, nblk, first ? 1 : 0, last ? 1 : 0, state, dig, *virt);

@@ -257,11 +257,38 @@ __global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void hash_lde_leaves_kf_kern
     else return base[(size_t)i * n];
   };
   kf_zero();
-  for (uint32_t off = 0;; off += 17) {
-    const uint32_t rem = cols - off;
-    kf_absorb<V>(off, rem, get);
-    P2_KECCAK_FIXED_PERMUTE();
-    if (rem < 17) break;
+  if constexpr (!V) {
+    // every word is a load: software pipeline -- the 17 loads of block b + 1 are issued before the permutation of block b and
+    // land under its 4 309 instructions (the array lives in hipcc's registers across the asm block; kf_check.py watches them)
+    uint64_t x[17];
+    // words of the rate block at `off`; the last block is ragged: rem < 17 words, then the 0x01 of the padding, then zeros
+    auto load_block = [&](uint32_t off) {
+      const uint32_t rem = cols - off;
+#pragma unroll
+      for (int w = 0; w < 17; w++) x[w] = (uint32_t)w < rem ? base[(size_t)(off + w) * n] : ((uint32_t)w == rem ? (uint64_t)1 : (uint64_t)0);
+    };
+    load_block(0);
+    for (uint32_t off = 0;;) {
+      const bool last = cols - off < 17;
+      kf_for<0, 17>([&](auto wc) {
+        constexpr int w = decltype(wc)::value;
+        const uint64_t xw = x[w];
+        const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
+        P2_KF_XOR(w, lo, hi);
+      });
+      if (last) P2_KF_XOR(16, 0u, 0x80000000u);
+      off += 17;
+      if (!last) load_block(off);
+      P2_KECCAK_FIXED_PERMUTE();  // (the one call site of this kernel)
+      if (last) break;
+    }
+  } else {
+    for (uint32_t off = 0;; off += 17) {
+      const uint32_t rem = cols - off;
+      kf_absorb<V>(off, rem, get);
+      P2_KECCAK_FIXED_PERMUTE();
+      if (rem < 17) break;
+    }
   }
   dig[(size_t)c * n + k] = kf_digest();
 }

@@ -202,7 +202,17 @@ def main():
     top = base + 50 + NTEMP
     w("// GENERATED by gen_keccak_fixed.py -- do not edit.  Keccak-f[1600], 24 rounds unrolled, explicit VGPRs (see the generator).\n")
     w(f"#define P2_KF_BASE {base}\n#define P2_KF_TOP {top}  /* first register above the block's */\n")
-    w("#define P2_KECCAK_FIXED_PERMUTE() asm volatile( \\\n")
+    # every instruction of the block is 8 bytes (VOP3, or VOP2 + literal; iota halves that are inline constants are forced to
+    # the 64-bit encoding) and the block starts 8-byte aligned: a stream of 8-byte instructions that sits at 4 mod 8 fetches
+    # measurably slower (MI355X_MICROARCH.md, "code-placement sensitivity"; P2_KF_PHASE_TEST shifts it on purpose)
+    # every instruction of the block is 8 bytes (VOP3, or VOP2 + literal; iota halves that are inline constants are forced to
+    # the 64-bit encoding), so the block's start decides where ALL of them sit relative to the 8-byte fetch granule -- and a
+    # MIXED stream of full-rate and half-rate 8-byte instructions is sensitive to that (profiles/r03_ubench.txt, sweep 4):
+    # starting at 4 mod 8 it runs at the blended rate (Keccak-f 11.3 Gperm/s with 2-4 waves per SIMD), starting 8-byte aligned
+    # everything runs at the half rate (8.9) -- except for a LONE wave, which is faster aligned (8.0 vs 6.8).  PH = number of
+    # s_nop behind a 64-byte alignment: 1 for throughput kernels, 0 for the latency-bound tree tails.
+    w("#define P2_KECCAK_FIXED_PERMUTE() P2_KECCAK_FIXED_PERMUTE_PH(1)\n")
+    w("#define P2_KECCAK_FIXED_PERMUTE_PH(PH) asm volatile(\".p2align 6\\n .rept \" #PH \"\\n s_nop 0\\n .endr\\n\" \\\n")
     for o, d, srcs in alloc:
         if o.kind in ("X3", "CHI"):
             w(f'  "v_bitop3_b32 v{d}, v{srcs[0]}, v{srcs[1]}, v{srcs[2]} bitop3:{hex(o.imm)}\\n" \\\n')
@@ -211,7 +221,10 @@ def main():
         else:
             rnd = int(o.dst[1:].split("_")[0])
             k = (RC[rnd] >> (32 * o.imm)) & 0xFFFFFFFF
-            w(f'  "v_xor_b32 v{d}, {hex(k)}, v{srcs[0]}\\n" \\\n')
+            if k <= 64:  # an inline constant: VOP2 would be 4 bytes
+                w(f'  "v_xor_b32_e64 v{d}, {k}, v{srcs[0]}\\n" \\\n')
+            else:
+                w(f'  "v_xor_b32 v{d}, {hex(k)}, v{srcs[0]}\\n" \\\n')
     for d, s in moves:
         w(f'  "v_mov_b32 v{d}, v{s}\\n" \\\n')
     w(f'  ::: "v{top - 1}")\n')

@@ -133,6 +133,7 @@ __device__ __forceinline__ uint64_t krot(uint64_t x) {
 #define P2_KF_XOR(i, lo, hi) ((void)(lo), (void)(hi))
 #define P2_KF_GET(i, lo, hi) ((lo) = 0, (hi) = 0)
 #define P2_KECCAK_FIXED_PERMUTE() ((void)0)
+#define P2_KECCAK_FIXED_PERMUTE_PH(PH) ((void)0)
 #endif
 
 // st[x + 5y]

@@ -265,7 +265,11 @@ __global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void hash_lde_leaves_kf_kern
     auto load_block = [&](uint32_t off) {
       const uint32_t rem = cols - off;
 #pragma unroll
+#ifdef P2_KF_NOLOAD  /* timing experiment only (scratch/): what the kernel costs without its memory traffic */
+      for (int w = 0; w < 17; w++) x[w] = (uint32_t)w < rem ? (uint64_t)(k + off + w) : ((uint32_t)w == rem ? (uint64_t)1 : (uint64_t)0);
+#else
       for (int w = 0; w < 17; w++) x[w] = (uint32_t)w < rem ? base[(size_t)(off + w) * n] : ((uint32_t)w == rem ? (uint64_t)1 : (uint64_t)0);
+#endif
     };
     load_block(0);
     for (uint32_t off = 0;;) {
@@ -292,6 +296,61 @@ __global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void hash_lde_leaves_kf_kern
   }
   dig[(size_t)c * n + k] = kf_digest();
 }
+// KeccakHash<25>::two_to_one (keccak_two_to_one of keccak.hpp) on the fixed registers: Keccak-256(left[25] || right[25])[..25].
+// PH = code-placement phase of the permutation block (keccak_fixed.inc): 1 for levels with many nodes, 0 when a SIMD holds a
+// lone wave (the tails, the small levels).
+template <int PH>
+__device__ __forceinline__ dig_t kf_two_to_one(const dig_t &l, const dig_t &r) {
+  uint64_t w[7];
+  w[0] = l.w[0];
+  w[1] = l.w[1];
+  w[2] = l.w[2];
+  w[3] = (l.w[3] & 0xFFULL) | (r.w[0] << 8);
+  w[4] = (r.w[0] >> 56) | (r.w[1] << 8);
+  w[5] = (r.w[1] >> 56) | (r.w[2] << 8);
+  w[6] = (r.w[2] >> 56) | ((r.w[3] & 0xFFULL) << 8) | (0x01ULL << 16);
+  kf_for<0, 7>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const uint64_t x = w[i];
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    P2_KF_SET(i, lo, hi);
+  });
+  kf_for<7, 25>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    P2_KF_SET(i, 0u, (i == 16 ? 0x80000000u : 0u));
+  });
+  if constexpr (PH == 0) P2_KECCAK_FIXED_PERMUTE_PH(0);  // (the macro stringifies its argument: literals only)
+  else P2_KECCAK_FIXED_PERMUTE_PH(1);
+  return kf_digest();
+}
+template <int PH>
+__global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void merkle_level_kf_kernel(const dig_t *__restrict__ in, dig_t *__restrict__ out, uint32_t m) {
+  const uint32_t half = m >> 1;
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = blockIdx.y;
+  if (k >= half) return;
+  const dig_t l = in[(size_t)c * m + k], r = in[(size_t)c * m + k + half];
+  out[(size_t)c * half + k] = kf_two_to_one<PH>(l, r);
+}
+// merkle_tail_kernel<0> on the fixed registers.  The level loop holds ONE permutation call site; a lane has at most one node
+// per level (the launcher switches to the tail at <= 2 * blockDim nodes per coset).
+__global__ __launch_bounds__(1024) P2_KF_KERNEL_ATTR void merkle_tail_kf_kernel(dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per) {
+  const uint32_t c = blockIdx.x;
+  while (m > cap_per) {
+    const uint32_t half = m >> 1;
+    const dig_t *in = lvl + (size_t)c * m;
+    dig_t *out = lvl + (size_t)cosets * m + (size_t)c * half;
+    const uint32_t k = threadIdx.x;
+    if (k < half) {
+      const dig_t l = in[k], r = in[k + half];
+      out[k] = kf_two_to_one<0>(l, r);
+    }
+    __syncthreads();
+    lvl += (size_t)cosets * m;
+    m = half;
+  }
+}
+
 // hash_lde_absorb_kernel with the state in fixed registers between the HBM round trips
 template <bool V>
 __global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void hash_lde_absorb_kf_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
@@ -440,9 +499,13 @@ __global__ __launch_bounds__(1024) void merkle_tail_kernel(dig_t *lvl, uint32_t 
 }
 void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc) {
   if (m <= cap_per) return;
-  ProfScope ps(prc ? "merkle_tail_kernel<1>" : "merkle_tail_kernel<0>", 96.0 * cosets * (double)(m - cap_per));
   uint32_t threads = m / 2 >= 1024 ? 1024 : (m / 2 >= 64 ? m / 2 : 64);
+  ProfScope ps(prc ? "merkle_tail_kernel<1>" : ((P2_KECCAK_FIXED && m / 2 <= threads) ? "merkle_tail_kf_kernel" : "merkle_tail_kernel<0>"),
+               96.0 * cosets * (double)(m - cap_per));
   if (prc) hipLaunchKernelGGL(merkle_tail_kernel<1>, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per, prc);
+#if P2_KECCAK_FIXED
+  else if (m / 2 <= threads) hipLaunchKernelGGL(merkle_tail_kf_kernel, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per);
+#endif
   else hipLaunchKernelGGL(merkle_tail_kernel<0>, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per, prc);
 }
 
@@ -513,8 +576,18 @@ void hash_fri_leaves(hipStream_t st, const gl_t *vals, uint32_t lg_npc, uint32_t
 void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m, const gl_t *prc) {
   uint32_t half = m >> 1;
   uint32_t threads = half >= 256 ? 256 : 64;
-  ProfScope ps(prc ? "merkle_level_kernel<1>" : "merkle_level_kernel<0>", 96.0 * cosets * (double)half);
+  const bool kf_big = P2_KECCAK_FIXED && !prc && (size_t)half * cosets >= (size_t)2 * 1024 * 64;
+  const bool kf_small = P2_KECCAK_FIXED && !prc && !kf_big && threads == 256;
+  ProfScope ps(prc ? "merkle_level_kernel<1>" : (kf_big ? "merkle_level_kf_kernel<1>" : (kf_small ? "merkle_level_kf_kernel<0>" : "merkle_level_kernel<0>")),
+               96.0 * cosets * (double)half);
   if (prc) hipLaunchKernelGGL(merkle_level_kernel<1>, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out, m, prc);
+#if P2_KECCAK_FIXED
+  // >= 2 waves per SIMD on the whole chip (2 * 1024 SIMDs * 64 lanes): throughput placement; below: a SIMD sees a lone wave
+  else if ((size_t)half * cosets >= (size_t)2 * 1024 * 64)
+    hipLaunchKernelGGL(merkle_level_kf_kernel<1>, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out, m);
+  else if (threads == 256)
+    hipLaunchKernelGGL(merkle_level_kf_kernel<0>, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out, m);
+#endif
   else hipLaunchKernelGGL(merkle_level_kernel<0>, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out, m, prc);
 }
 

@@ -25,11 +25,12 @@ __global__ __launch_bounds__(256, K) void kperm(uint64_t *out, int iters, uint64
   for (int i = 0; i < 25; i++) s ^= st[i];
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
+static int g_gens = 1;
 template <int K>
 static void run(uint64_t *out, int iters) {
   hipEvent_t a, b;
   hipEventCreate(&a); hipEventCreate(&b);
-  const int blocks = 256 * K;
+  const int blocks = 256 * K * g_gens;
   hipLaunchKernelGGL(kperm<K>, dim3(blocks), dim3(256), 0, 0, out, 2, 12345ull);
   hipDeviceSynchronize();
   hipEventRecord(a);
@@ -42,8 +43,9 @@ static void run(uint64_t *out, int iters) {
   printf("K=%d  %8.3f ms  %7.2f Gperm/s  check %016llx\n", K, ms, perms / (ms * 1e-3) / 1e9, (unsigned long long)h[1]);
 }
 int main(int argc, char **argv) {
+  if (argc > 2) g_gens = atoi(argv[2]);
   const int iters = argc > 1 ? atoi(argv[1]) : 4000;
-  uint64_t *out; hipMalloc(&out, 8ull * 256 * 8 * 256);
+  uint64_t *out; hipMalloc(&out, 8ull * 256 * 8 * 256 * 64);
   run<1>(out, iters); run<2>(out, iters); run<3>(out, iters); run<4>(out, iters); run<5>(out, iters); run<6>(out, iters); run<7>(out, iters);
   return 0;
 }

@@ -19,6 +19,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(P2_KF_BASE))) v
     const uint64_t v = seed * (i + 1) + threadIdx.x + blockIdx.x * 977;
     KF_SET(i, (uint32_t)v, (uint32_t)(v >> 32));
   });
+#ifdef STAGGER
+  {  // desynchronise the waves of a SIMD: they all run the same B,B,A stream
+    const int w = (threadIdx.x >> 6) + 4 * (blockIdx.x & 3);
+    for (int i = 0; i < (w * STAGGER) % 16; i++) __builtin_amdgcn_s_sleep(1);
+  }
+#endif
   for (int it = 0; it < iters; it++) {
     P2_KECCAK_FIXED_PERMUTE();
     KF_XOR(3, (uint32_t)it, 0u);
@@ -34,18 +40,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(P2_KF_BASE))) v
 }
 int main(int argc, char **argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 3000;
-  uint64_t *out; hipMalloc(&out, 8ull * 256 * 8 * 256);
+  uint64_t *out; hipMalloc(&out, 8ull * 256 * 8 * 256 * 64);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  const int gens = argc > 2 ? atoi(argv[2]) : 1;  // generations of blocks: > 1 = block turnover as in the prover's kernels
   for (int K : {1, 2, 3, 4}) {
-    const int blocks = 256 * K;
+    const int blocks = 256 * K * gens;
     hipLaunchKernelGGL(kperm, dim3(blocks), dim3(256), 0, 0, out, 2, 12345ull);
     hipDeviceSynchronize();
+    const int reps = argc > 4 ? atoi(argv[4]) : 1;  // back-to-back launches inside the timed region
     hipEventRecord(a);
-    hipLaunchKernelGGL(kperm, dim3(blocks), dim3(256), 0, 0, out, iters, 12345ull);
+    for (int r = 1; r < reps; r++) hipLaunchKernelGGL(kperm, dim3(blocks), dim3(256), 0, 0, out, iters, 12345ull);
+    const int lds = argc > 3 ? atoi(argv[3]) : 0;   // dynamic LDS bytes per block: caps the blocks per CU (160 KB / lds)
+    hipLaunchKernelGGL(kperm, dim3(blocks), dim3(256), lds, 0, out, iters, 12345ull);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     uint64_t h[4]; hipMemcpy(h, out, 32, hipMemcpyDeviceToHost);
-    printf("K=%d  %8.3f ms  %7.2f Gperm/s  check %016llx\n", K, ms, (double)iters * blocks * 256 / (ms * 1e-3) / 1e9, (unsigned long long)h[1]);
+    printf("K=%d  %8.3f ms  %7.2f Gperm/s  check %016llx\n", K, ms, (double)iters * blocks * 256 * reps / (ms * 1e-3) / 1e9, (unsigned long long)h[1]);
   }
   return 0;
 }

@@ -48,6 +48,7 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(kperm, dim3(blocks), dim3(256), 0, 0, out, 2, 12345ull);
     hipDeviceSynchronize();
     const int reps = argc > 4 ? atoi(argv[4]) : 1;  // back-to-back launches inside the timed region
+    if (argc > 5) hipLaunchKernelGGL(kperm, dim3(256 * K), dim3(256), 0, 0, out, atoi(argv[5]), 999ull);  // untimed busy launch right before
     hipEventRecord(a);
     for (int r = 1; r < reps; r++) hipLaunchKernelGGL(kperm, dim3(blocks), dim3(256), 0, 0, out, iters, 12345ull);
     const int lds = argc > 3 ? atoi(argv[3]) : 0;   // dynamic LDS bytes per block: caps the blocks per CU (160 KB / lds)

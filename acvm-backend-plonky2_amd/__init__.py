@@ -18,6 +18,8 @@ from .prover import (  # noqa: F401
     P2GpuError,
     device_info,
     init,
+    host_array,
+    host_free,
     ifft_batch,
     lde_batch,
     commit_values,

@@ -17,22 +17,37 @@
 
 namespace p2 {
 
-__global__ void ext_powers_bitrev_kernel(ext_t base, uint32_t d, gl_t *out) {
+// sq[b] = base^(2^b) of the two bases (host: d squarings each): a lane multiplies the ones its exponent's bits select --
+// half the products of squaring in every lane, and both tables of a proof (zeta, g*zeta) in ONE launch (grid.y)
+struct ExtSquares {
+  ext_t sq[2][32];
+};
+__global__ __launch_bounds__(256) void ext_powers_bitrev_kernel(ExtSquares S, uint32_t d, gl_t *out0, gl_t *out1) {
   const uint32_t n = 1u << d;
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  uint32_t e = bitrev32(p, d);
-  ext_t acc = ext_from(1), cur = base;
-  for (uint32_t b = 0; b < d; b++) {
-    if ((e >> b) & 1) acc = ext_mul(acc, cur);
-    cur = ext_mul(cur, cur);
-  }
+  const uint32_t which = blockIdx.y;
+  const uint32_t e = bitrev32(p, d);
+  ext_t acc = ext_from(1);
+  for (uint32_t b = 0; b < d; b++)
+    if ((e >> b) & 1) acc = ext_mul(acc, S.sq[which][b]);
+  gl_t *out = which ? out1 : out0;
   out[p] = acc.c0;
   out[(size_t)n + p] = acc.c1;
 }
-void ext_powers_bitrev(hipStream_t st, ext_t base, uint32_t d, gl_t *out) {
+void ext_powers_bitrev2(hipStream_t st, ext_t base0, ext_t base1, uint32_t d, gl_t *out0, gl_t *out1) {
+  ExtSquares S;
+  ext_t a = base0, b = base1;
+  for (uint32_t i = 0; i < 32; i++) {
+    S.sq[0][i] = a;
+    S.sq[1][i] = b;
+    if (i + 1 < d) {
+      a = ext_mul(a, a);
+      b = ext_mul(b, b);
+    }
+  }
   uint32_t n = 1u << d;
-  hipLaunchKernelGGL(ext_powers_bitrev_kernel, dim3((n + 255) / 256), dim3(256), 0, st, base, d, out);
+  hipLaunchKernelGGL(ext_powers_bitrev_kernel, dim3((n + 255) / 256, 2), dim3(256), 0, st, S, d, out0, out1);
 }
 
 // grid (parts, cols)
@@ -185,16 +200,32 @@ __global__ __launch_bounds__(256) void reduce_columns_kernel(const gl_t *__restr
   acc[p] = a0;
   acc[(size_t)n + p] = a1;
 }
-// list[0] = count, list[1..] = indices of the DENSE columns (class 2), ascending (one thread: W is a few hundred)
-__global__ void compact_nonzero_kernel(const uint32_t *flags, uint32_t cols, uint32_t *list) {
-  if (blockIdx.x || threadIdx.x) return;
-  uint32_t k = 0;
-  for (uint32_t j = 0; j < cols; j++)
-    if (flags[j] >= 2) list[1 + k++] = j;  // dense, or class 3 (coefficients in memory, no shortcut)
-  list[0] = k;
+// list[0] = count, list[1..] = indices of the DENSE columns (class 2; or class 3: coefficients in memory, no shortcut),
+// ascending.  One block: ballot + popcount per wave, wave totals through LDS (a serial loop over a few hundred dependent
+// loads was 28 us on the critical path of every proof)
+__global__ __launch_bounds__(256) void compact_nonzero_kernel(const uint32_t *flags, uint32_t cols, uint32_t *list) {
+  __shared__ uint32_t wcnt[4];
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  uint32_t base = 0;
+  for (uint32_t j0 = 0; j0 < cols; j0 += 256) {
+    const uint32_t j = j0 + threadIdx.x;
+    const bool f = j < cols && flags[j] >= 2;
+    const unsigned long long m = __ballot(f);
+    if (lane == 0) wcnt[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = base, tot = 0;
+    for (uint32_t q = 0; q < 4; q++) {
+      if (q < w) off += wcnt[q];
+      tot += wcnt[q];
+    }
+    if (f) list[1 + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;
+    __syncthreads();
+    base += tot;
+  }
+  if (threadIdx.x == 0) list[0] = base;
 }
 void compact_nonzero(hipStream_t st, const uint32_t *flags, uint32_t cols, uint32_t *list) {
-  hipLaunchKernelGGL(compact_nonzero_kernel, dim3(1), dim3(64), 0, st, flags, cols, list);
+  hipLaunchKernelGGL(compact_nonzero_kernel, dim3(1), dim3(256), 0, st, flags, cols, list);
 }
 // fold[e] = sum over the class 1 columns j of apow[2 (j0 + j) + e] * val[j]   (e = 0, 1)
 __global__ __launch_bounds__(256) void class1_fold_kernel(const uint32_t *cls, const gl_t *val, uint32_t cols, const gl_t *apow,

@@ -170,7 +170,8 @@ void fill_witness(hipStream_t st, gl_t *wires, const uint8_t *row_gate, const Ga
 
 // ---- fri.hip ----
 // pw[p] = base^(bitrev_d(p)) over the extension: out [2][n]
-void ext_powers_bitrev(hipStream_t st, ext_t base, uint32_t d, gl_t *out);
+// out[p] = base^(bitrev_d(p)) (c0 plane, then c1 plane), for two bases in one launch
+void ext_powers_bitrev2(hipStream_t st, ext_t base0, ext_t base1, uint32_t d, gl_t *out0, gl_t *out1);
 // partial dot products: for each column c of coeffs [cols][n]: sum_p coeffs[c][p] * pw[p]; parts per column
 // hints (optional): class 0 columns open to zero; class 1 columns to val[c] times the unit column's partial sums
 // (basis_partial [parts][2], left by an earlier eval_columns launch over that one column)

@@ -230,6 +230,71 @@ P2_HD dig_t keccak_two_to_one(const dig_t &l, const dig_t &r) {
   return dig_from_state(st);
 }
 
+// ---- ONE Keccak-f spread over 25 lanes (lane L = x + 5y of a 32-lane half; two permutations per wave) -----------------
+// For the top of a Merkle tree, where a level has fewer nodes than the chip has SIMDs and its cost is the LATENCY of one
+// permutation: a lone wave issues one VALU instruction per 5.3-6.1 cycles however independent they are
+// (profiles/r03_ubench.txt), so 4 359 instructions are 7.4 us per level; here a round is 16 VALU instructions and three
+// ds_bpermute stages (theta column parity | theta row neighbours | the three rho-rotated lanes chi needs, fetched straight
+// from where pi takes them): 3.5 us per permutation with <= 2 waves per CU, 4.5 with one per SIMD (the CU's LDS crossbar
+// serves ~1 bpermute per 6 cycles: 8.9 with 8 waves) -- scratch/ubench/coop2.hip, checked there against the fixed-register form.
+struct KeccakCoopLane {
+  uint32_t col[4];       // byte addresses (lane * 4) of the four column mates (y + 1 .. y + 4)
+  uint32_t rm, rp;       // row neighbours x - 1, x + 1
+  uint32_t b0, b1, b2;   // pi^-1 of (x, y), (x + 1, y), (x + 2, y)
+  uint32_t s, swap;      // rho: v_alignbit shift, and whether the halves trade places first (rotation >= 32, or 0)
+  uint32_t m0;           // all ones in lane 0 (iota)
+};
+P2_HD KeccakCoopLane keccak_coop_lane(uint32_t lane) {
+  const int rot[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+  const uint32_t base = lane & 32u, L0 = lane & 31u, L = L0 < 25 ? L0 : 0;
+  const int x = L % 5, y = L / 5;
+  KeccakCoopLane c;
+  for (int i = 0; i < 4; i++) c.col[i] = (base + (L + 5 * (i + 1)) % 25) * 4;
+  c.rm = (base + (x + 4) % 5 + 5 * y) * 4;
+  c.rp = (base + (x + 1) % 5 + 5 * y) * 4;
+  // B[X][Y] = rot(A[x'][y']) with y' = X and 2x' + 3y' = Y (mod 5), i.e. x' = 3 (Y - 3X) mod 5
+  auto src = [&](int X, int Y) { return (uint32_t)((((Y - 3 * X) % 5 + 5) % 5) * 3 % 5 + 5 * X); };
+  c.b0 = (base + src(x, y)) * 4;
+  c.b1 = (base + src((x + 1) % 5, y)) * 4;
+  c.b2 = (base + src((x + 2) % 5, y)) * 4;
+  const int r = rot[L];
+  c.swap = (r == 0 || r >= 32) ? 1u : 0u;   // (shift 0 of the alignbit pair below IS a swap: rotation 0 swaps twice)
+  c.s = (uint32_t)(32 - (r & 31)) & 31u;
+  c.m0 = L0 == 0 ? 0xFFFFFFFFu : 0u;
+  return c;
+}
+// (lo, hi) = this lane's 64-bit word of the state; lanes 25..31 of a half carry garbage nobody reads
+__device__ __forceinline__ void keccak_f1600_coop(uint32_t &lo, uint32_t &hi, const KeccakCoopLane &c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr uint64_t RC[24] = {
+      0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+      0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+      0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+      0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+      0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+      0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+  auto bp = [](uint32_t addr, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr, (int)v); };
+  auto x3 = [](uint32_t a, uint32_t b, uint32_t d) { return __builtin_amdgcn_bitop3_b32(a, b, d, 0x96); };
+#pragma unroll
+  for (int r = 0; r < 24; r++) {
+    const uint32_t t0 = bp(c.col[0], lo), t1 = bp(c.col[1], lo), t2 = bp(c.col[2], lo), t3 = bp(c.col[3], lo);
+    const uint32_t u0 = bp(c.col[0], hi), u1 = bp(c.col[1], hi), u2 = bp(c.col[2], hi), u3 = bp(c.col[3], hi);
+    const uint32_t cl = x3(x3(lo, t0, t1), t2, t3), ch = x3(x3(hi, u0, u1), u2, u3);
+    const uint32_t ml = bp(c.rm, cl), mh = bp(c.rm, ch), pl = bp(c.rp, cl), ph = bp(c.rp, ch);
+    lo = x3(lo, ml, __builtin_amdgcn_alignbit(pl, ph, 31));
+    hi = x3(hi, mh, __builtin_amdgcn_alignbit(ph, pl, 31));
+    const uint32_t L_ = c.swap ? hi : lo, H_ = c.swap ? lo : hi;
+    const uint32_t rl = __builtin_amdgcn_alignbit(L_, H_, c.s), rh = __builtin_amdgcn_alignbit(H_, L_, c.s);
+    const uint32_t a0 = bp(c.b0, rl), a1 = bp(c.b1, rl), a2 = bp(c.b2, rl);
+    const uint32_t h0 = bp(c.b0, rh), h1 = bp(c.b1, rh), h2 = bp(c.b2, rh);
+    lo = __builtin_amdgcn_bitop3_b32(a0, a1, a2, 0xD2) ^ ((uint32_t)RC[r] & c.m0);
+    hi = __builtin_amdgcn_bitop3_b32(h0, h1, h2, 0xD2) ^ ((uint32_t)(RC[r] >> 32) & c.m0);
+  }
+#else
+  (void)lo, (void)hi, (void)c;  // host pass of hipcc: parsed only
+#endif
+}
+
 // BytesHash<25>::to_vec: 7-byte little-endian chunks -> 4 field elements
 P2_HD void dig_to_elems(const dig_t &d, gl_t out[4]) {
   const uint64_t M56 = 0x00FFFFFFFFFFFFFFULL;

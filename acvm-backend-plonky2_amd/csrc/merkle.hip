@@ -351,6 +351,54 @@ __global__ __launch_bounds__(1024) P2_KF_KERNEL_ATTR void merkle_tail_kf_kernel(
   }
 }
 
+// Up to four levels of the top of a Keccak tree per launch, every node hashed by 25 lanes (keccak_f1600_coop): a block of
+// four waves (one per SIMD: eight permutations at a time) owns the complete sub-tree under ONE node of the last level it
+// computes -- with the (k, k + half) pairing of merkle_level_kernel that is the nodes k0 + j * mf of every level above
+// (mf = nodes per coset of that last level) -- so the levels inside a launch need a block barrier only; inputs of the
+// first level come from memory, later ones from LDS, every level goes out to memory for the query paths.
+// grid = cosets * mf blocks.  m = nodes per coset of the input level, levels in [1, 4].
+__global__ __launch_bounds__(256) void merkle_coop_kernel(dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t levels) {
+  __shared__ uint64_t nodes[16][4];
+  const uint32_t mf = m >> levels;
+  const uint32_t c = blockIdx.x / mf, k0 = blockIdx.x % mf;
+  const uint32_t lane = threadIdx.x & 63u, L = lane & 31u, slot = (threadIdx.x >> 6) * 2 + (lane >> 5);
+  const KeccakCoopLane cl = keccak_coop_lane(lane);
+  uint32_t cnt = 1u << levels;  // this block's nodes of the current input level
+  for (uint32_t lv = 0; lv < levels; lv++) {
+    const uint32_t half = cnt >> 1;
+    if (slot < half) {
+      // state words 0..6 = left[25] || right[25] || 0x01 pad, word 16 = the 0x80 that ends the rate (kf_two_to_one):
+      // with D[0..3] = left.w, D[4..7] = right.w, word L is (D[L] low part) | (D[L + 1] << 8)
+      uint64_t p = 0, q = 0;
+      if (L < 7) {
+        if (lv == 0) {
+          const dig_t *in = lvl + (size_t)c * m;
+          const dig_t *l = in + k0 + (size_t)slot * mf, *r = in + k0 + (size_t)(slot + half) * mf;
+          p = L < 4 ? l->w[L] : r->w[L - 4];
+          if (L >= 3) q = r->w[L - 3];
+        } else {
+          p = L < 4 ? nodes[slot][L] : nodes[slot + half][L - 4];
+          if (L >= 3) q = nodes[slot + half][L - 3];
+        }
+      }
+      uint64_t w = L < 3 ? p : (L == 3 ? (p & 0xFFULL) : (p >> 56));
+      if (L >= 3 && L < 7) w |= (L == 6 ? ((q & 0xFFULL) << 8) | (1ULL << 16) : (q << 8));
+      if (L >= 7) w = L == 16 ? 0x8000000000000000ULL : 0ULL;
+      uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+      keccak_f1600_coop(lo, hi, cl);
+      if (L < 4) {
+        const uint64_t o = L == 3 ? (uint64_t)(lo & 0xFFu) : (((uint64_t)hi << 32) | lo);
+        lvl[(size_t)cosets * m + (size_t)c * (m >> 1) + k0 + (size_t)slot * mf].w[L] = o;
+        nodes[slot][L] = o;  // slot < half is read by this slot only (as its left child); right children sit at >= half
+      }
+    }
+    __syncthreads();
+    lvl += (size_t)cosets * m;
+    m >>= 1;
+    cnt = half;
+  }
+}
+
 // hash_lde_absorb_kernel with the state in fixed registers between the HBM round trips
 template <bool V>
 __global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void hash_lde_absorb_kf_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
@@ -497,8 +545,42 @@ __global__ __launch_bounds__(1024) void merkle_tail_kernel(dig_t *lvl, uint32_t 
     m = half;
   }
 }
+// P2GPU_COOP_TAIL=0: the one-lane-per-node tail of rounds 1-2 (A/B measurements)
+static bool coop_tail_on() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("P2GPU_COOP_TAIL");
+    v = (e && *e == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
 void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc) {
   if (m <= cap_per) return;
+#if P2_KECCAK_FIXED
+  if (!prc && coop_tail_on()) {
+    // Keccak: a level with more than 2 048 nodes (two per wave: one wave per SIMD on the chip) is still cheaper one lane
+    // per node (7.5 us); below that the 25-lane form (3.5-5 us per level), four levels per launch
+    while (m > cap_per) {
+      if ((size_t)cosets * (m >> 1) > 2048 && (m >> 1) >= 256) {
+        merkle_level(st, lvl, lvl + (size_t)cosets * m, cosets, m, prc);
+        lvl += (size_t)cosets * m;
+        m >>= 1;
+        continue;
+      }
+      uint32_t levels = 0;
+      while (levels < 4 && (m >> levels) > cap_per) levels++;
+      {
+        ProfScope ps("merkle_coop_kernel", 96.0 * cosets * (double)(m - (m >> levels)));
+        hipLaunchKernelGGL(merkle_coop_kernel, dim3(cosets * (m >> levels)), dim3(256), 0, st, lvl, cosets, m, levels);
+      }
+      for (uint32_t i = 0; i < levels; i++) {
+        lvl += (size_t)cosets * m;
+        m >>= 1;
+      }
+    }
+    return;
+  }
+#endif
   uint32_t threads = m / 2 >= 1024 ? 1024 : (m / 2 >= 64 ? m / 2 : 64);
   ProfScope ps(prc ? "merkle_tail_kernel<1>" : ((P2_KECCAK_FIXED && m / 2 <= threads) ? "merkle_tail_kf_kernel" : "merkle_tail_kernel<0>"),
                96.0 * cosets * (double)(m - cap_per));

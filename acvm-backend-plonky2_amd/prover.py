@@ -111,6 +111,10 @@ def load_library():
     lib.p2gpu_hash_rows.argtypes = [vp, sz, sz, u8p]
     lib.p2gpu_field_selftest.argtypes = [vp, vp, sz, vp]
     lib.p2gpu_device_info.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(sz)]
+    lib.p2gpu_host_alloc.argtypes = [sz]
+    lib.p2gpu_host_alloc.restype = vp
+    lib.p2gpu_host_free.argtypes = [vp]
+    lib.p2gpu_host_free.restype = None
     _LIB = lib
     return lib
 
@@ -134,6 +138,49 @@ def init(devices=(0,)):
     lib = load_library()
     devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
     _check(lib.p2gpu_init(devs, len(devices)))
+
+
+class _HostBlock:
+    """Owner of one ``p2gpu_host_alloc`` block; the numpy view made over it keeps this object alive."""
+
+    def __init__(self, nbytes):
+        self._lib = load_library()
+        self.ptr = self._lib.p2gpu_host_alloc(nbytes)
+        if not self.ptr:
+            raise P2GpuError(-3, self._lib.p2gpu_last_error().decode(errors="replace"))
+        self.buf = (ctypes.c_uint8 * max(1, nbytes)).from_address(self.ptr)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self.buf = None
+            self._lib.p2gpu_host_free(self.ptr)
+            self.ptr = None
+
+
+def host_array(shape, dtype=np.uint64):
+    """A numpy array in page-locked host memory (``p2gpu_host_alloc``): a wire matrix built in place here uploads by
+    direct DMA inside ``prove`` instead of being staged by the HIP runtime on the calling thread."""
+    shape = (shape,) if isinstance(shape, int) else tuple(shape)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+    blk = _HostBlock(nbytes)
+    arr = np.frombuffer(blk.buf, dtype=dtype, count=nbytes // np.dtype(dtype).itemsize).reshape(shape)
+    _HOST_BLOCKS[id(blk)] = blk  # freed by host_free(arr) or at interpreter exit; a view may outlive `arr` itself
+    arr.flags.writeable = True
+    return arr
+
+
+_HOST_BLOCKS = {}
+
+
+def host_free(arr):
+    """Release the block behind an array returned by ``host_array`` (the array must not be used afterwards)."""
+    addr = arr.ctypes.data
+    for k, blk in list(_HOST_BLOCKS.items()):
+        if blk.ptr == addr:
+            del _HOST_BLOCKS[k]
+            blk.__del__()
+            return
+    raise P2GpuError(-1, "host_free: not an array from host_array")
 
 
 def device_info():

@@ -98,9 +98,18 @@ typedef struct {
   uint64_t pow_witness;
 } p2gpu_timings;
 
-/* Select the device of this process (one process per GPU: pass exactly one id; more is P2GPU_E_ARG).
- * device_ids may be NULL for {current device}. */
+/* Select the device(s) of this process.  One id (or NULL = {device 0}): one process per GPU -- replicas, or the ranks of a
+ * proof sharded over processes (p2gpu_circuit_set_shard*).  Several ids (at most 8, repeats allowed): THIS process drives
+ * them all; every handle created afterwards is a device group and each prove call is ONE proof coset-sharded over the
+ * group from threads inside the call (the shape `circuit_data.prove(pw)`, prove_action.rs:96, can call).  Out-of-range
+ * ids or more than 8: P2GPU_E_ARG. */
 int p2gpu_init(const int *device_ids, int n_devices);
+/* Page-locked ("pinned") host memory for the wire matrix handed to p2gpu_prove / _routed / _sparse -- what the caller
+ * would otherwise hold in a Vec<F> (the witness the reference builds before prove_action.rs:96).  Uploads from it are
+ * direct DMA and do not occupy the calling thread; any other host pointer still works (the HIP runtime stages it).
+ * NULL on failure (p2gpu_last_error). */
+void *p2gpu_host_alloc(size_t bytes);
+void p2gpu_host_free(void *p);
 
 int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out);
 void p2gpu_circuit_destroy(p2gpu_circuit *c);

@@ -257,6 +257,32 @@ def test_prove_sparse_matches_the_full_matrix(pkg, orc, gpu, d, mix, ncols):
     cd.close()
 
 
+@pytest.mark.parametrize("d,mix", [(9, "ecdsa"), (13, "sha")])
+def test_page_locked_host_witness(pkg, orc, gpu, d, mix):
+    """p2gpu_host_alloc / p2gpu_host_free: a wire matrix built in page-locked memory proves to the same bytes through every
+    host entry (full matrix, compact form), the block can be reused for the next witness and released."""
+    blob, wires = pkg.make_circuit(d, mix, 11)
+    cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
+    expect, _ = oc.prove(wires)
+    wp = pkg.host_array(wires.shape)
+    assert wp.dtype == np.uint64 and wp.shape == wires.shape and wp.flags.c_contiguous
+    wp[...] = wires
+    assert cd.prove(wp).to_bytes() == expect
+    w2 = wp.reshape(234, -1)
+    if mix == "sha":
+        nz = np.nonzero(w2[233])[0]
+        assert cd.prove_sparse(w2, 80, int(nz[0]) if nz.size == 1 else 0).to_bytes() == expect
+    blob2, wires2 = pkg.make_circuit(d, mix, 12)     # same shape, another witness in the same block
+    wp[...] = wires2
+    cd2, oc2 = pkg.CircuitData(blob2), orc.OracleCircuit(blob2)
+    assert cd2.prove(wp).to_bytes() == oc2.prove(wires2)[0]
+    pkg.host_free(wp)
+    with pytest.raises(pkg.P2GpuError):
+        pkg.host_free(np.zeros(4, dtype=np.uint64))
+    cd.close()
+    cd2.close()
+
+
 @pytest.mark.parametrize("d,mix,npi", [(6, "arith", 1), (8, "sha", 4), (9, "ecdsa", 9), (12, "ecdsa", 20)])
 def test_public_inputs_proof_bytes_match_oracle(pkg, orc, gpu, d, mix, npi):
     """PoseidonGate rows + Poseidon public_inputs_hash (InnerHasher) on the GPU path."""

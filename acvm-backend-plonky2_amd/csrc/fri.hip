@@ -50,15 +50,14 @@ void ext_powers_bitrev2(hipStream_t st, ext_t base0, ext_t base1, uint32_t d, gl
   hipLaunchKernelGGL(ext_powers_bitrev_kernel, dim3((n + 255) / 256, 2), dim3(256), 0, st, S, d, out0, out1);
 }
 
-// grid (parts, cols)
-__global__ __launch_bounds__(256) void eval_columns_kernel(const gl_t *__restrict__ coeffs, uint32_t d,
-                                                           const gl_t *__restrict__ pw, uint32_t parts,
-                                                           gl_t *__restrict__ partial, const uint32_t *__restrict__ colnz,
-                                                           const gl_t *__restrict__ colval,
-                                                           const gl_t *__restrict__ basis_partial) {
+// one (part, column) block of an opening: the dot product of 1/parts of the column's coefficients with the powers of the
+// point (both coordinates), left as a partial sum for the host to add up
+__device__ __forceinline__ void eval_column_block(const gl_t *__restrict__ coeffs, uint32_t d, const gl_t *__restrict__ pw,
+                                                  uint32_t parts, gl_t *__restrict__ partial, const uint32_t *__restrict__ colnz,
+                                                  const gl_t *__restrict__ colval, const gl_t *__restrict__ basis_partial,
+                                                  uint32_t part, uint32_t col) {
   __shared__ gl_t s0[256], s1[256];
   const uint32_t n = 1u << d;
-  const uint32_t part = blockIdx.x, col = blockIdx.y;
   if (colnz != nullptr && colnz[col] < 2) {  // (class 3 columns have their coefficients in memory: the plain dot product)
     // class 0: the zero polynomial opens to zero; class 1: v times the unit column's polynomial, whose partial
     // sums an earlier launch left in basis_partial [parts][2]
@@ -100,12 +99,39 @@ __global__ __launch_bounds__(256) void eval_columns_kernel(const gl_t *__restric
     partial[((size_t)col * parts + part) * 2 + 1] = s1[0];
   }
 }
+// grid (parts, cols)
+__global__ __launch_bounds__(256) void eval_columns_kernel(const gl_t *__restrict__ coeffs, uint32_t d,
+                                                           const gl_t *__restrict__ pw, uint32_t parts,
+                                                           gl_t *__restrict__ partial, const uint32_t *__restrict__ colnz,
+                                                           const gl_t *__restrict__ colval,
+                                                           const gl_t *__restrict__ basis_partial) {
+  eval_column_block(coeffs, d, pw, parts, partial, colnz, colval, basis_partial, blockIdx.x, blockIdx.y);
+}
+// every batch of a proof's openings in ONE launch (grid.y runs over the columns of all segments): six launches of which four
+// were too small to fill the chip were 0.14 ms on the critical path of a proof
+__global__ __launch_bounds__(256) void eval_columns_multi_kernel(EvalSegs S, uint32_t d, uint32_t parts) {
+  uint32_t col = blockIdx.y, k = 0;
+  while (k + 1 < S.count && col >= S.seg[k].cols) {
+    col -= S.seg[k].cols;
+    k++;
+  }
+  const bool h = k == S.hinted;
+  eval_column_block(S.seg[k].coeffs, d, S.seg[k].pw, parts, S.seg[k].partial, h ? S.cls : nullptr, h ? S.val : nullptr,
+                    h ? S.basis_partial : nullptr, blockIdx.x, col);
+}
 void eval_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *pw, uint32_t parts,
                   gl_t *partial, const ColHints *hints, const gl_t *basis_partial) {
   if (!cols) return;
   ProfScope ps("eval_columns_kernel", 8.0 * cols * (double)((size_t)1 << d));
   hipLaunchKernelGGL(eval_columns_kernel, dim3(parts, cols), dim3(256), 0, st, coeffs, d, pw, parts, partial,
                      hints ? hints->cls : nullptr, hints ? hints->val : nullptr, basis_partial);
+}
+void eval_columns_multi(hipStream_t st, const EvalSegs &S, uint32_t d, uint32_t parts) {
+  uint32_t cols = 0;
+  for (uint32_t k = 0; k < S.count; k++) cols += S.seg[k].cols;
+  if (!cols) return;
+  ProfScope ps("eval_columns_multi_kernel", 8.0 * cols * (double)((size_t)1 << d));
+  hipLaunchKernelGGL(eval_columns_multi_kernel, dim3(parts, cols), dim3(256), 0, st, S, d, parts);
 }
 
 // block = 64 positions x 4 column groups: group g sums the columns j = g mod 4 (8 loads in flight

@@ -112,7 +112,10 @@ void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d,
                      uint32_t nblk, bool first, bool last, uint64_t *state, dig_t *dig, const VirtCols *virt = nullptr);
 void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m, const gl_t *prc = nullptr);
 // every level below one with m <= 4096 nodes per coset, down to cap_per nodes per coset, in one launch
-void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc = nullptr);
+bool merkle_tail_fuses(const gl_t *prc);
+// host_mirror (optional, page-locked, [cosets][cap_per]): returns true when the final level was also written there
+bool merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc = nullptr,
+                 dig_t *host_mirror = nullptr);
 
 // ---- plonk.hip ----
 struct ZsArgs {
@@ -177,6 +180,19 @@ void ext_powers_bitrev2(hipStream_t st, ext_t base0, ext_t base1, uint32_t d, gl
 // (basis_partial [parts][2], left by an earlier eval_columns launch over that one column)
 void eval_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *pw, uint32_t parts,
                   gl_t *partial /* [cols][parts][2] */, const ColHints *hints = nullptr, const gl_t *basis_partial = nullptr);
+// the same for up to six batches of columns in one launch; segment `hinted` (UINT32_MAX: none) carries the column classes
+struct EvalSegs {
+  struct Seg {
+    const gl_t *coeffs;  // [cols][n]
+    const gl_t *pw;      // powers of the point, [2][n]
+    gl_t *partial;       // [cols][parts][2]
+    uint32_t cols;
+  } seg[6];
+  uint32_t count = 0, hinted = UINT32_MAX;
+  const uint32_t *cls = nullptr;
+  const gl_t *val = nullptr, *basis_partial = nullptr;
+};
+void eval_columns_multi(hipStream_t st, const EvalSegs &S, uint32_t d, uint32_t parts);
 // acc[2][n] (+)= sum_j apow[j0 + j] * coeffs[j][p]
 void reduce_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *apow /*[.][2]*/,
                     uint32_t j0, gl_t *acc, bool accumulate, const uint32_t *nzlist = nullptr, const gl_t *basis = nullptr,

@@ -332,6 +332,40 @@ __global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void merkle_level_kf_kernel(
   const dig_t l = in[(size_t)c * m + k], r = in[(size_t)c * m + k + half];
   out[(size_t)c * half + k] = kf_two_to_one<PH>(l, r);
 }
+// Up to three single-lane levels in one launch, for the levels that are latency-bound (at most one wave per SIMD on the chip)
+// but still too wide for the 25-lane form: a block of four waves takes 64 neighbouring nodes of its last level and everything
+// above them (nodes k + j * mf of every level, as in merkle_coop_kernel); level 1 on all four waves, level 2 on two, level 3 on
+// one, children through LDS.  Saves the store -> end of kernel -> launch -> load (3.6 of a level's 11 us) between fused levels.
+// grid = cosets * mf / 64, mf = m >> levels a multiple of 64.
+__global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void merkle_levels_kf_kernel(dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t levels) {
+  __shared__ dig_t nodes[4][64];
+  const uint32_t mf = m >> levels, bpc = mf >> 6;
+  const uint32_t c = blockIdx.x / bpc, t = threadIdx.x & 63u, g = threadIdx.x >> 6;
+  const uint32_t k = (blockIdx.x % bpc) * 64 + t;
+  uint32_t cnt = 1u << levels;
+#pragma unroll 1
+  for (uint32_t lv = 0; lv < levels; lv++) {
+    const uint32_t half = cnt >> 1;
+    if (g < half) {
+      dig_t l, r;
+      if (lv == 0) {
+        const dig_t *in = lvl + (size_t)c * m;
+        l = in[k + (size_t)g * mf];
+        r = in[k + (size_t)(g + half) * mf];
+      } else {
+        l = nodes[g][t];
+        r = nodes[g + half][t];
+      }
+      const dig_t o = kf_two_to_one<0>(l, r);
+      lvl[(size_t)cosets * m + (size_t)c * (m >> 1) + k + (size_t)g * mf] = o;
+      nodes[g][t] = o;  // (g < half: read by this lane only; the right children sit at >= half)
+    }
+    __syncthreads();
+    lvl += (size_t)cosets * m;
+    m >>= 1;
+    cnt = half;
+  }
+}
 // merkle_tail_kernel<0> on the fixed registers.  The level loop holds ONE permutation call site; a lane has at most one node
 // per level (the launcher switches to the tail at <= 2 * blockDim nodes per coset).
 __global__ __launch_bounds__(1024) P2_KF_KERNEL_ATTR void merkle_tail_kf_kernel(dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per) {
@@ -357,7 +391,10 @@ __global__ __launch_bounds__(1024) P2_KF_KERNEL_ATTR void merkle_tail_kf_kernel(
 // (mf = nodes per coset of that last level) -- so the levels inside a launch need a block barrier only; inputs of the
 // first level come from memory, later ones from LDS, every level goes out to memory for the query paths.
 // grid = cosets * mf blocks.  m = nodes per coset of the input level, levels in [1, 4].
-__global__ __launch_bounds__(256) void merkle_coop_kernel(dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t levels) {
+// mirror (optional, page-locked host memory): the level with cap_per nodes per coset is ALSO stored there, [coset][cap_per] --
+// the transcript reads the cap from it after the stream sync, without a copy kernel in between.
+__global__ __launch_bounds__(256) void merkle_coop_kernel(dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t levels, dig_t *mirror,
+                                                          uint32_t cap_per) {
   __shared__ uint64_t nodes[16][4];
   const uint32_t mf = m >> levels;
   const uint32_t c = blockIdx.x / mf, k0 = blockIdx.x % mf;
@@ -389,6 +426,7 @@ __global__ __launch_bounds__(256) void merkle_coop_kernel(dig_t *lvl, uint32_t c
       if (L < 4) {
         const uint64_t o = L == 3 ? (uint64_t)(lo & 0xFFu) : (((uint64_t)hi << 32) | lo);
         lvl[(size_t)cosets * m + (size_t)c * (m >> 1) + k0 + (size_t)slot * mf].w[L] = o;
+        if (mirror != nullptr && (m >> 1) == cap_per) mirror[(size_t)c * cap_per + k0 + (size_t)slot * mf].w[L] = o;
         nodes[slot][L] = o;  // slot < half is read by this slot only (as its left child); right children sit at >= half
       }
     }
@@ -554,31 +592,47 @@ static bool coop_tail_on() {
   }
   return v == 1;
 }
-void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc) {
-  if (m <= cap_per) return;
+// true: merkle_tail takes a Keccak tree from the first level with at most one wave per SIMD on the chip (fused launches);
+// false: from tail_nodes() nodes per coset, as the one-block-per-coset kernels need
+bool merkle_tail_fuses(const gl_t *prc) { return P2_KECCAK_FIXED && !prc && coop_tail_on(); }
+bool merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc, dig_t *host_mirror) {
+  if (m <= cap_per) return false;
 #if P2_KECCAK_FIXED
   if (!prc && coop_tail_on()) {
     // Keccak: a level with more than 2 048 nodes (two per wave: one wave per SIMD on the chip) is still cheaper one lane
     // per node (7.5 us); below that the 25-lane form (3.5-5 us per level), four levels per launch
+    bool mirrored = false;
     while (m > cap_per) {
       if ((size_t)cosets * (m >> 1) > 2048 && (m >> 1) >= 256) {
-        merkle_level(st, lvl, lvl + (size_t)cosets * m, cosets, m, prc);
-        lvl += (size_t)cosets * m;
-        m >>= 1;
+        // single-lane levels; the latency-bound ones (<= one wave per SIMD on the chip) up to three per launch
+        uint32_t lv = 1;
+        if ((size_t)cosets * (m >> 1) <= (size_t)1024 * 64)
+          while (lv < 3 && (size_t)cosets * (m >> (lv + 1)) > 2048 && (m >> (lv + 1)) >= 256 && (m >> (lv + 1)) >= cap_per) lv++;
+        if (lv == 1) {
+          merkle_level(st, lvl, lvl + (size_t)cosets * m, cosets, m, prc);
+        } else {
+          ProfScope ps("merkle_levels_kf_kernel", 96.0 * cosets * (double)(m - (m >> lv)));
+          hipLaunchKernelGGL(merkle_levels_kf_kernel, dim3(cosets * ((m >> lv) >> 6)), dim3(256), 0, st, lvl, cosets, m, lv);
+        }
+        for (uint32_t i = 0; i < lv; i++) {
+          lvl += (size_t)cosets * m;
+          m >>= 1;
+        }
         continue;
       }
       uint32_t levels = 0;
       while (levels < 4 && (m >> levels) > cap_per) levels++;
       {
         ProfScope ps("merkle_coop_kernel", 96.0 * cosets * (double)(m - (m >> levels)));
-        hipLaunchKernelGGL(merkle_coop_kernel, dim3(cosets * (m >> levels)), dim3(256), 0, st, lvl, cosets, m, levels);
+        hipLaunchKernelGGL(merkle_coop_kernel, dim3(cosets * (m >> levels)), dim3(256), 0, st, lvl, cosets, m, levels, host_mirror, cap_per);
+        if (host_mirror != nullptr && (m >> levels) == cap_per) mirrored = true;  // (a cap this wide ends on a plain level launch)
       }
       for (uint32_t i = 0; i < levels; i++) {
         lvl += (size_t)cosets * m;
         m >>= 1;
       }
     }
-    return;
+    return mirrored;
   }
 #endif
   uint32_t threads = m / 2 >= 1024 ? 1024 : (m / 2 >= 64 ? m / 2 : 64);
@@ -589,6 +643,7 @@ void merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32
   else if (m / 2 <= threads) hipLaunchKernelGGL(merkle_tail_kf_kernel, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per);
 #endif
   else hipLaunchKernelGGL(merkle_tail_kernel<0>, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per, prc);
+  return false;
 }
 
 void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig, const gl_t *prc,

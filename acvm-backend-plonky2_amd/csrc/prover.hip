@@ -378,9 +378,17 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
   const uint32_t C = c->C, CL = b.ncl;
   size_t m = m0;
   const size_t cap_target = ((size_t)1 << c->cap_h) >> c->rate_bits;
+  // a tree every rank holds completely (constants/sigmas, FRI steps >= 1) needs no exchange -- except in
+  // the one-rank plumbing test, where every tree goes through the transport
+  const bool local = CL == C && !(c->shard_world == 1 && sharded(c));
+  // the kernel that computes the cap level stores it in page-locked host memory as well when it can (merkle_tail): no
+  // copy kernel between the last level and the transcript's sync
+  dig_t *mirror = local && m0 > cap_target ? c->pin.take<dig_t>(C * cap_target) : nullptr;
+  bool mirrored = false;
   for (size_t l = 1; l < b.level_off.size(); l++) {
-    if (m <= tail_nodes()) {  // the rest of the tree in one launch
-      merkle_tail(c->stream, b.dig.p + b.level_off[l - 1], CL, (uint32_t)m, (uint32_t)cap_target, hprc(c));
+    // the rest of the tree in merkle_tail: a few launches of several levels each (Keccak), or one (Poseidon)
+    if (merkle_tail_fuses(hprc(c)) ? (size_t)CL * (m >> 1) <= (size_t)1024 * 64 : m <= tail_nodes()) {
+      mirrored = merkle_tail(c->stream, b.dig.p + b.level_off[l - 1], CL, (uint32_t)m, (uint32_t)cap_target, hprc(c), mirror);
       m = cap_target;
       break;
     }
@@ -388,13 +396,12 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
     m >>= 1;
   }
   const size_t cap_per = m;
-  dig_t *raw = c->pin.take<dig_t>(C * cap_per);  // [global coset][cap_per]; pinned: the D2H below is a true async copy
+  dig_t *raw = mirrored ? mirror : c->pin.take<dig_t>(C * cap_per);  // [global coset][cap_per]; pinned: the D2H below is a true async copy
   if (!raw) return pin_exhausted();
-  // a tree every rank holds completely (constants/sigmas, FRI steps >= 1) needs no exchange -- except in
-  // the one-rank plumbing test, where every tree goes through the transport
-  if (CL == C && !(c->shard_world == 1 && sharded(c))) {
-    HIP_TRY(hipMemcpyAsync(raw, b.dig.p + b.level_off.back(), C * cap_per * sizeof(dig_t), hipMemcpyDeviceToHost,
-                           c->stream));
+  if (local) {
+    if (!mirrored)
+      HIP_TRY(hipMemcpyAsync(raw, b.dig.p + b.level_off.back(), C * cap_per * sizeof(dig_t), hipMemcpyDeviceToHost,
+                             c->stream));
     g_hp.mark("enq(cap)");
     if (int rc_ = wait_stream(c)) return rc_;
     g_hp.mark("WAIT(cap)");
@@ -702,15 +709,19 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
       if (c->sparse_coeffs.p) eval_columns(st, c->sparse_coeffs.p, 1, d, c->pw.p, parts, c->sparse_partial.p);
     }
     size_t base = 0;
+    EvalSegs es;  // the four batches at zeta and Z at g * zeta: one launch
     for (int o = 0; o < 4; o++) {
-      const bool hw = structured && oracles[o] == &c->wires;
-      eval_columns(st, oracles[o]->coeffs.p, oracles[o]->cols, d, c->pw.p, parts, c->partial.p + base * parts * 2,
-                   hw ? &wh : nullptr, hw ? c->sparse_partial.p : nullptr);
+      if (structured && oracles[o] == &c->wires) {
+        es.hinted = es.count;
+        es.cls = wh.cls;
+        es.val = wh.val;
+        es.basis_partial = c->sparse_partial.p;
+      }
+      es.seg[es.count++] = {oracles[o]->coeffs.p, c->pw.p, c->partial.p + base * parts * 2, oracles[o]->cols};
       base += oracles[o]->cols;
     }
-    {
-      eval_columns(st, c->zp.coeffs.p, K, d, c->pw.p + 2 * n, parts, c->partial.p + base * parts * 2);
-    }
+    es.seg[es.count++] = {c->zp.coeffs.p, c->pw.p + 2 * n, c->partial.p + base * parts * 2, K};
+    eval_columns_multi(st, es, d, parts);
     const size_t npart = (size_t)(nall + K) * parts * 2;
     gl_t *part = c->pin.take<gl_t>(npart);
     if (!part) return pin_exhausted();

@@ -868,3 +868,23 @@ def test_other_cap_heights_and_pow_bits(pkg, orc, gpu, d, mix, cap_h, pow_bits, 
     assert pkg.commit_values(v, 3, cap_h) == orc.commit_values(v, 3, cap_h)
     cd.close()
     oc.close()
+
+
+@pytest.mark.parametrize("env", [{"P2GPU_COOP_TAIL": "0"}, {"P2GPU_HOST_PRESCAN": "0"}])
+def test_measurement_switches_keep_the_bytes(pkg, gpu, env):
+    """The A/B switches DESIGN.md quotes select the older kernels / paths (one lane per node in the tree tops, the whole wire
+    matrix over PCIe): read once per process, so a child process proves a golden circuit with the switch set and the digest
+    must still be the committed one."""
+    import subprocess
+    import sys
+
+    g = max(_gold("proof_digests.json"), key=lambda x: x["degree_bits"])
+    code = (
+        "import hashlib, sys; sys.path.insert(0, %r); import __graft_entry__ as ge; pkg = ge.load_package();"
+        "out = pkg.make_circuit(%d, %r, %d, num_public_inputs=%d); cd = pkg.CircuitData(out[0]);"
+        "p = cd.prove(out[1], public_inputs=(out[2] if %d else ())); print('DIGEST', hashlib.sha256(p.to_bytes()).hexdigest())"
+        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), g["degree_bits"], g["mix"], g["seed"], g["public_inputs"],
+           g["public_inputs"]))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert ("DIGEST " + g["proof_sha256"]) in r.stdout, r.stdout[-500:]

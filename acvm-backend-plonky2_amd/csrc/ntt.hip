@@ -302,7 +302,11 @@ __device__ __forceinline__ void round_regs(gl_t *lds, const PassArgs &A, uint32_
       const gl_t *tp = tw + lo;
 #pragma unroll
       for (int e = 1; e < R; e++) {
+#ifdef NTT_EXP_NOTW   // timing experiment only (wrong results): what waiting for the twiddle loads costs
+        t[e] = (gl_t)(size_t)tp;
+#else
         t[e] = *tp;
+#endif
         tp += tstride;
       }
     }
@@ -391,7 +395,11 @@ __global__ __launch_bounds__(TBC ? NTT_THREADS : 256, NTT_MIN_WAVES) void ntt_pa
 #pragma unroll
     for (int i = 0; i < PER; i++) {
       g[i] = glin ? g0 + (uint32_t)i * gstep : gidx(threadIdx.x + i * NT, hi_base, lo0, A.s, A.tb);
+#ifdef NTT_EXP_NOLOAD   // timing experiment only (wrong results): what the load phase costs
+      x[i] = (gl_t)g[i] * 0x9E3779B97F4A7C15ULL;
+#else
       x[i] = src[g[i]];
+#endif
     }
     if (scale) {
       gl_t sc[PER];
@@ -441,6 +449,9 @@ __global__ __launch_bounds__(TBC ? NTT_THREADS : 256, NTT_MIN_WAVES) void ntt_pa
       for (int i = 0; i < PER; i++) x[i] = gl_canon(x[i]);  // LDS holds congruent, not canonical, words
 #endif
     }
+#ifdef NTT_EXP_NOSTORE  // timing experiment only (wrong results): what the store phase costs
+    if ((x[0] ^ x[1] ^ x[2] ^ x[3] ^ x[4] ^ x[5] ^ x[6] ^ x[7]) == 0x1234567ULL)
+#endif
 #pragma unroll
     for (int i = 0; i < PER; i++) dst[glin ? g0 + (uint32_t)i * gstep : gidx(threadIdx.x + i * NT, hi_base, lo0, A.s, A.tb)] = x[i];
   } else {
@@ -597,6 +608,8 @@ __global__ __launch_bounds__(256) void structured_fill_kernel(gl_t *dst, uint32_
   }
 }
 
+static void ntt_passes(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
+                       const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_all, const uint32_t *colnz);
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
                const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_cols, const ColHints *hints) {
   if (cols == 0) return;
@@ -609,6 +622,32 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
   }
   const uint32_t d = plan->d;
   const size_t np = plan->passes.size();
+  // A transform of several passes leaves its intermediate in dst between them.  With every column in one launch per pass
+  // that intermediate (8n words per column for an LDE) is long gone from the 256 MB memory-side cache when the next pass
+  // reads it; in groups of columns whose dst fits, the second pass finds it there and overwrites it in place: the
+  // intermediate's round trip never reaches HBM (P2GPU_NTT_GROUP_MB: group size, 0 = one launch per pass as before)
+  static const size_t group_bytes = [] {
+    const char *e = getenv("P2GPU_NTT_GROUP_MB");
+    return (size_t)(e ? atoi(e) : 0) << 20;
+  }();
+  const uint32_t stride_all = stride_cols ? stride_cols : cols;
+  const uint32_t *colnz = hints ? hints->cls : nullptr;
+  if (np >= 2 && group_bytes) {
+    const size_t per_col = (size_t)cosets * 8 << d;
+    const uint32_t gcols = (uint32_t)std::max<size_t>(1, group_bytes / per_col);
+    if (gcols < cols) {
+      for (uint32_t c0 = 0; c0 < cols; c0 += gcols)
+        ntt_passes(st, plan, src + ((size_t)c0 << d), dst + ((size_t)c0 << d), std::min(gcols, cols - c0), cosets, scale, post,
+                   src_per_coset, cm, stride_all, colnz ? colnz + c0 : nullptr);
+      return;
+    }
+  }
+  ntt_passes(st, plan, src, dst, cols, cosets, scale, post, src_per_coset, cm, stride_all, colnz);
+}
+static void ntt_passes(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
+                       const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_all, const uint32_t *colnz) {
+  const uint32_t d = plan->d;
+  const size_t np = plan->passes.size();
   for (size_t i = 0; i < np; i++) {
     const NttPass &ps = plan->passes[i];
     PassArgs A;
@@ -619,12 +658,12 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     A.post = (i == np - 1) ? post : 1;
     A.d = d;
     A.s = ps.s; A.a = ps.a; A.tb = ps.tb;
-    A.cols = stride_cols ? stride_cols : cols;  // column stride between cosets (a launch may cover a column chunk)
+    A.cols = stride_all;  // column stride between cosets (a launch may cover a column chunk)
     A.src_single = (i == 0 && !src_per_coset) ? 1 : 0;
     A.coset_first = cm.first;
     A.coset_stride = cm.stride;
     A.nrounds = ps.nrounds;
-    A.colnz = hints ? hints->cls : nullptr;
+    A.colnz = colnz;
     for (int k = 0; k < MAX_ROUNDS; k++) { A.r[k] = ps.r[k]; A.tw_off[k] = ps.tw_off[k]; }
     const uint32_t TB = A.a + A.tb;
     const uint32_t tiles = 1u << (d - TB);

@@ -146,6 +146,31 @@ def mix_ceiling(kernel):
     return VALU_HALF_MEASURED, "half-rate class (field arithmetic: carry chains + v_mad_u64_u32)"
 
 
+def counter_clock(kernel, wave_instr_per_launch, launches_per_sec):
+    """Cycle-level view of a kernel from the committed counter pass (profiles/rNN_clock.txt = scratch/clock_pmc.sh: GRBM_GUI_ACTIVE
+    per dispatch): cycles per VALU wave-instruction per SIMD -- what the issue rules of profiles/r03_ubench.txt bound, whatever
+    the clock -- the shader clock that pass saw, and the clock THIS run's kernel time implies at the same cycles per instruction.
+    The chip lowers its clock under these kernels (1.7-2.0 GHz in the Keccak streams, 2.1-2.3 in the field arithmetic): the gap
+    between frac_of_mix_ceiling (instructions per SECOND) and 1 is mostly that, not stalls."""
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_clock.txt")))
+    if not files:
+        return {}
+    section = "ecdsa" if PROFILE_TAG else "sha"
+    cur = None
+    for line in open(files[-1]):
+        if line.startswith("=="):
+            cur = "ecdsa" if "ecdsa" in line else "sha"
+        m = re.match(r"^(.*?)\s+launches\s+\d+ avg\s+([\d.]+) us\s+clock ([\d.]+) GHz\s+cycles/VALU wave-instr/SIMD ([\d.]+)", line)
+        if m and cur == section and m.group(1).strip() == kernel:
+            cpi = float(m.group(4))
+            return {"cycles_per_valu_wave_instr": cpi, "clock_ghz_counter_pass": float(m.group(3)),
+                    "clock_ghz_implied_this_run": cpi * wave_instr_per_launch / 1024.0 * launches_per_sec / 1e9,
+                    "cycles_source": os.path.basename(files[-1]) + " (GRBM_GUI_ACTIVE / 8 XCDs per dispatch, SQ_INSTS_VALU / 1024 SIMDs)",
+                    "stream_cycles_per_instr_ubench": 3.16 if "hash_lde" in kernel or "merkle" in kernel else None}
+    return {}
+
+
 def issue_roofline(kernel, launches_per_sec):
     """VALU issue side of a kernel: lane-instructions per launch from the committed SQ pass (SQ_INSTS_VALU x 64) x live
     launches/s of kernel time, against the guide's peak and against the ceiling of the kernel's own instruction mix."""
@@ -157,10 +182,12 @@ def issue_roofline(kernel, launches_per_sec):
             insts = json.load(fh)["kernels"][kernel]["SQ_INSTS_VALU"] * 64.0
         rate = insts * launches_per_sec
         ceil, why = mix_ceiling(kernel)
-        return {"bound": "valu-issue", "lane_instr_per_launch": insts, "achieved": rate, "peak": VALU_PEAK,
-                "unit": "lane-instr/s", "frac": rate / VALU_PEAK, "source": os.path.basename(f),
-                "peak_source": "MI355X_MICROARCH.md (2 cycles per wave64 VALU at 2.4 GHz), reproduced for the full-rate opcodes in profiles/r03_ubench.txt",
-                "mix_ceiling": ceil, "frac_of_mix_ceiling": rate / ceil, "mix_ceiling_source": why}
+        out = {"bound": "valu-issue", "lane_instr_per_launch": insts, "achieved": rate, "peak": VALU_PEAK,
+               "unit": "lane-instr/s", "frac": rate / VALU_PEAK, "source": os.path.basename(f),
+               "peak_source": "MI355X_MICROARCH.md (2 cycles per wave64 VALU at 2.4 GHz), reproduced for the full-rate opcodes in profiles/r03_ubench.txt",
+               "mix_ceiling": ceil, "frac_of_mix_ceiling": rate / ceil, "mix_ceiling_source": why}
+        out.update(counter_clock(kernel, insts / 64.0, launches_per_sec))
+        return out
     except Exception:
         return None
 

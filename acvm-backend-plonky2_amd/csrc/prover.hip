@@ -973,6 +973,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     }
     per_query = ptrs.size() - start;
   }
+  g_hp.mark("ptrs");
   if (ptrs.size() > c->gather_cap) {
     set_err("internal: gather buffer too small");
     return P2GPU_E_DEVICE;
@@ -985,6 +986,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   {
     gather_u64(st, c->gather_ptrs.p, (uint32_t)ptrs.size(), c->gather_out.p);
   }
+  g_hp.mark("launch(gather)");
   if (!sharded(c)) {
     HIP_TRY(hipMemcpyAsync(gathered, c->gather_out.p, ptrs.size() * 8, hipMemcpyDeviceToHost, st));
     g_hp.mark("enq(gather)");
@@ -993,10 +995,13 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   } else {
     // each rank gathered the queries that fall into its cosets: exchange and pick every query
     // from its owner
+    g_hp.mark("enq(gather)");
     if (int rc = shard_allgather(c, c->gather_out.p, c->xchg_recv.p, ptrs.size() * 8)) return rc;
+    g_hp.mark("xchg(gather)");
     std::vector<gl_t> all((size_t)world * ptrs.size());
     HIP_TRY(hipMemcpyAsync(all.data(), c->xchg_recv.p, all.size() * 8, hipMemcpyDeviceToHost, st));
     if (int rc_ = wait_stream(c)) return rc_;
+    g_hp.mark("WAIT(gather)");
     for (size_t qi = 0; qi < qidx.size(); qi++) {
       const uint32_t owner = brev((uint32_t)(qidx[qi] >> d), lgC) % (uint32_t)world;
       memcpy(&gathered[qi * per_query], &all[(size_t)owner * ptrs.size() + qi * per_query], per_query * 8);

@@ -33,7 +33,14 @@ import os
 import sys
 import time
 
-import numpy as np
+# The MI355X boxes show 256 hardware threads and grant a cgroup quota of 16 CPUs: thread pools sized by the former (OpenMP in
+# torch / numpy's BLAS: 256 spinning workers per process) run into the quota and every thread of the process group -- the
+# prover's host threads too -- is frozen for the rest of the 100 ms period (cpu.stat nr_throttled; eight ranks make it eight times
+# worse).  Nothing here needs them; the oracle leg sets its own count (_oracle_leg).
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

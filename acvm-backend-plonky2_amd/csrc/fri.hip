@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256) void eval_columns_kernel(const gl_t *__restric
 }
 // every batch of a proof's openings in ONE launch (grid.y runs over the columns of all segments): six launches of which four
 // were too small to fill the chip were 0.14 ms on the critical path of a proof
-__global__ __launch_bounds__(256) void eval_columns_multi_kernel(EvalSegs S, uint32_t d, uint32_t parts) {
-  uint32_t col = blockIdx.y, k = 0;
+__global__ __launch_bounds__(256) void eval_columns_multi_kernel(EvalSegs S, uint32_t d, uint32_t parts, uint32_t col0) {
+  uint32_t col = col0 + blockIdx.y, k = 0;
   while (k + 1 < S.count && col >= S.seg[k].cols) {
     col -= S.seg[k].cols;
     k++;
@@ -126,12 +126,14 @@ void eval_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d,
   hipLaunchKernelGGL(eval_columns_kernel, dim3(parts, cols), dim3(256), 0, st, coeffs, d, pw, parts, partial,
                      hints ? hints->cls : nullptr, hints ? hints->val : nullptr, basis_partial);
 }
-void eval_columns_multi(hipStream_t st, const EvalSegs &S, uint32_t d, uint32_t parts) {
+void eval_columns_multi(hipStream_t st, const EvalSegs &S, uint32_t d, uint32_t parts, uint32_t col0, uint32_t ncols) {
   uint32_t cols = 0;
   for (uint32_t k = 0; k < S.count; k++) cols += S.seg[k].cols;
+  if (col0 >= cols) return;
+  cols = std::min(cols - col0, ncols);
   if (!cols) return;
   ProfScope ps("eval_columns_multi_kernel", 8.0 * cols * (double)((size_t)1 << d));
-  hipLaunchKernelGGL(eval_columns_multi_kernel, dim3(parts, cols), dim3(256), 0, st, S, d, parts);
+  hipLaunchKernelGGL(eval_columns_multi_kernel, dim3(parts, cols), dim3(256), 0, st, S, d, parts, col0);
 }
 
 // block = 64 positions x 4 column groups: group g sums the columns j = g mod 4 (8 loads in flight

@@ -192,7 +192,8 @@ struct EvalSegs {
   const uint32_t *cls = nullptr;
   const gl_t *val = nullptr, *basis_partial = nullptr;
 };
-void eval_columns_multi(hipStream_t st, const EvalSegs &S, uint32_t d, uint32_t parts);
+// (col0, ncols): the slice of the concatenated columns this launch evaluates (a rank's share of a sharded proof)
+void eval_columns_multi(hipStream_t st, const EvalSegs &S, uint32_t d, uint32_t parts, uint32_t col0 = 0, uint32_t ncols = UINT32_MAX);
 // acc[2][n] (+)= sum_j apow[j0 + j] * coeffs[j][p]
 void reduce_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t d, const gl_t *apow /*[.][2]*/,
                     uint32_t j0, gl_t *acc, bool accumulate, const uint32_t *nzlist = nullptr, const gl_t *basis = nullptr,

@@ -434,7 +434,8 @@ def main():
     # (the same binary reads 209 proofs/s over 48 timed proofs and 218 over 192); a short W would leave the timed
     # region on the ramp, so proofs continue until --clock-warmup-ms have passed since the first one
     extra_warm = 0
-    while (time.perf_counter() - tw0) * 1e3 < args.clock_warmup_ms and d <= 17:
+    # (not in the sharded mode: there every proof is a collective and the ranks must agree on their number)
+    while (time.perf_counter() - tw0) * 1e3 < args.clock_warmup_ms and d <= 17 and not sharded and not args.group:
         run(cds, 2 * S)
         extra_warm += 2 * S
     barrier()

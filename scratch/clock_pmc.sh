@@ -2,7 +2,7 @@
 # shader clock per kernel of the timed bench command: GRBM_GUI_ACTIVE / 8 XCDs / dispatch time (rocprofv3 --pmc, counters only)
 REPO=$(pwd); export TMPDIR=/tmp; cd /tmp
 OUT=$REPO/gpurun_out/prof_clock; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT -- python $REPO/bench.py --steps 5 --warmup 2 --in-flight 1 --timed-only "$@" > $OUT/log.txt 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT -- python $REPO/bench.py --steps 5 --warmup 2 --in-flight 1 --timed-only --clock-warmup-ms 0 "$@" > $OUT/log.txt 2>&1
 cd $REPO
 python - "$OUT" <<'PY'
 import csv,glob,collections,sys

@@ -10,7 +10,7 @@ cd /tmp
 TAG=${1:-run}; shift
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-CMD="python $REPO/bench.py --steps 5 --warmup 2 --in-flight 1 --timed-only $@"
+CMD="python $REPO/bench.py --steps 5 --warmup 2 --in-flight 1 --timed-only --clock-warmup-ms 0 $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1

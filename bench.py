@@ -477,7 +477,7 @@ def main():
         barrier()
         single_ms = pkg.parallel.max_over_ranks(time.perf_counter() - t1) / nlat * 1e3
     # (a) per-launch HIP events on the library's launch stream -> roofline of the dominant kernel
-    cd.set("profile", 1)
+    cd.set("profile", 2)   # 2: every launch the library wraps in a scope (1: only those moving >= 32 MB)
     P = max(1, args.profile_steps)
     run([cd], P)
     stats = cd.kernel_stats()

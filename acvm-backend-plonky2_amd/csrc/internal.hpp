@@ -113,6 +113,7 @@ void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d,
 void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m, const gl_t *prc = nullptr);
 // every level below one with m <= 4096 nodes per coset, down to cap_per nodes per coset, in one launch
 bool merkle_tail_fuses(const gl_t *prc);
+size_t merkle_tail_from(const gl_t *prc);
 // host_mirror (optional, page-locked, [cosets][cap_per]): returns true when the final level was also written there
 bool merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc = nullptr,
                  dig_t *host_mirror = nullptr);

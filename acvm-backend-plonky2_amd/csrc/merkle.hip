@@ -551,6 +551,30 @@ __global__ __launch_bounds__(256) void hash_fri_leaves_kernel(const gl_t *__rest
   }, prc);
 }
 
+// hash_fri_leaves_kernel<1> for the small trees of the later reduction steps: twelve lanes per leaf (poseidon_permute_coop),
+// the overwrite-mode sponge of hash_n_to_m_no_pad -- words 8b .. 8b + 7 of the leaf replace state words 0..7 before
+// permutation b.  Leaves of 2 << ab >= 8 words (a multiple of the rate).  One block = 16 leaves.
+__global__ __launch_bounds__(256) void hash_fri_leaves_coop_poseidon_kernel(const gl_t *__restrict__ vals, uint32_t lg_npc, uint32_t ab,
+                                                                            uint32_t cosets, dig_t *__restrict__ dig,
+                                                                            const gl_t *__restrict__ prc) {
+  const uint32_t npc = 1u << lg_npc, per = npc >> ab;
+  const uint32_t lane = threadIdx.x & 63u, i = lane & 15u;
+  const uint32_t slot = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + (lane >> 4);
+  if (slot >= cosets * per) return;  // (whole 16-lane groups leave together)
+  const uint32_t r = slot / per, kl = slot % per;
+  const gl_t *c0 = vals + (size_t)r * 2 * npc, *c1 = c0 + npc;
+  const PoseidonCoopLane cl = poseidon_coop_lane(lane);
+  gl_t x = 0;
+  for (uint32_t b = 0; b < (2u << ab) / 8; b++) {
+    if (i < 8) {
+      const uint32_t w = 8 * b + i, k = bitrev32(w >> 1, ab) * per + kl;
+      x = (w & 1) ? c1[k] : c0[k];
+    }
+    x = poseidon_permute_coop(x, prc, cl);
+  }
+  if (i < 4) dig[(size_t)r * per + kl].w[i] = x;
+}
+
 template <int H>
 __global__ __launch_bounds__(256) void merkle_level_kernel(const dig_t *__restrict__ in, dig_t *__restrict__ out,
                                                            uint32_t m, const gl_t *__restrict__ prc) {
@@ -583,6 +607,37 @@ __global__ __launch_bounds__(1024) void merkle_tail_kernel(dig_t *lvl, uint32_t 
     m = half;
   }
 }
+// merkle_coop_kernel for PoseidonHash: twelve lanes per permutation (poseidon_permute_coop), four per wave, sixteen per block of
+// four waves; up to five levels per launch (the first one on all sixteen slots).  two_to_one = the first four words of
+// permute(left[4] || right[4] || 0^4) (hashing.rs compress).
+__global__ __launch_bounds__(256) void merkle_coop_poseidon_kernel(dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t levels,
+                                                                   const gl_t *__restrict__ prc) {
+  __shared__ uint64_t nodes[32][4];
+  const uint32_t mf = m >> levels;
+  const uint32_t c = blockIdx.x / mf, k0 = blockIdx.x % mf;
+  const uint32_t lane = threadIdx.x & 63u, i = lane & 15u, slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
+  const PoseidonCoopLane cl = poseidon_coop_lane(lane);
+  uint32_t cnt = 1u << levels;
+  for (uint32_t lv = 0; lv < levels; lv++) {
+    const uint32_t half = cnt >> 1;
+    if (slot < half) {
+      gl_t x = 0;
+      if (i < 8) {
+        const uint32_t j = slot + (i < 4 ? 0u : half), w = i & 3u;
+        x = lv == 0 ? lvl[(size_t)c * m + k0 + (size_t)j * mf].w[w] : nodes[j][w];
+      }
+      x = poseidon_permute_coop(x, prc, cl);
+      if (i < 4) {
+        lvl[(size_t)cosets * m + (size_t)c * (m >> 1) + k0 + (size_t)slot * mf].w[i] = x;
+        nodes[slot][i] = x;  // slot < half is read by this slot only (as its left child); right children sit at >= half
+      }
+    }
+    __syncthreads();
+    lvl += (size_t)cosets * m;
+    m >>= 1;
+    cnt = half;
+  }
+}
 // P2GPU_COOP_TAIL=0: the one-lane-per-node tail of rounds 1-2 (A/B measurements)
 static bool coop_tail_on() {
   static int v = -1;
@@ -595,8 +650,35 @@ static bool coop_tail_on() {
 // true: merkle_tail takes a Keccak tree from the first level with at most one wave per SIMD on the chip (fused launches);
 // false: from tail_nodes() nodes per coset, as the one-block-per-coset kernels need
 bool merkle_tail_fuses(const gl_t *prc) { return P2_KECCAK_FIXED && !prc && coop_tail_on(); }
+// levels with at most this many nodes (all cosets together) go to merkle_tail (0: the per-coset rule of tail_nodes())
+size_t merkle_tail_from(const gl_t *prc) {
+  if (!coop_tail_on()) return 0;
+  if (prc) return 16384;                       // Poseidon: twelve lanes per node pay up to four waves per SIMD (~27 vs ~75 us per level)
+  return P2_KECCAK_FIXED ? (size_t)1024 * 64 : 0;  // Keccak: from one wave per SIMD
+}
 bool merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc, dig_t *host_mirror) {
   if (m <= cap_per) return false;
+  if (prc && coop_tail_on()) {
+    while (m > cap_per) {
+      if ((size_t)cosets * (m >> 1) > 16384) {
+        merkle_level(st, lvl, lvl + (size_t)cosets * m, cosets, m, prc);
+        lvl += (size_t)cosets * m;
+        m >>= 1;
+        continue;
+      }
+      uint32_t levels = 0;
+      while (levels < 5 && (m >> levels) > cap_per) levels++;
+      {
+        ProfScope ps("merkle_coop_poseidon_kernel", 96.0 * cosets * (double)(m - (m >> levels)));
+        hipLaunchKernelGGL(merkle_coop_poseidon_kernel, dim3(cosets * (m >> levels)), dim3(256), 0, st, lvl, cosets, m, levels, prc);
+      }
+      for (uint32_t q = 0; q < levels; q++) {
+        lvl += (size_t)cosets * m;
+        m >>= 1;
+      }
+    }
+    return false;
+  }
 #if P2_KECCAK_FIXED
   if (!prc && coop_tail_on()) {
     // Keccak: a level with more than 2 048 nodes (two per wave: one wave per SIMD on the chip) is still cheaper one lane
@@ -707,7 +789,9 @@ void hash_fri_leaves(hipStream_t st, const gl_t *vals, uint32_t lg_npc, uint32_t
   uint32_t per = (1u << lg_npc) >> ab;
   uint32_t threads = per >= 256 ? 256 : 64;
   ProfScope ps(prc ? "hash_fri_leaves_kernel<1>" : "hash_fri_leaves_kernel<0>", (16.0 * (1u << ab) + 32.0) * cosets * (double)per);
-  if (prc) hipLaunchKernelGGL(hash_fri_leaves_kernel<1>, dim3((per + threads - 1) / threads, cosets), dim3(threads), 0, st, vals, lg_npc, ab, dig, prc);
+  if (prc && coop_tail_on() && (2u << ab) >= 8 && (size_t)cosets * per <= 4096)  // latency-bound: 4 permutations of ~12 us instead of ~75
+    hipLaunchKernelGGL(hash_fri_leaves_coop_poseidon_kernel, dim3((cosets * per + 15) / 16), dim3(256), 0, st, vals, lg_npc, ab, cosets, dig, prc);
+  else if (prc) hipLaunchKernelGGL(hash_fri_leaves_kernel<1>, dim3((per + threads - 1) / threads, cosets), dim3(threads), 0, st, vals, lg_npc, ab, dig, prc);
   else hipLaunchKernelGGL(hash_fri_leaves_kernel<0>, dim3((per + threads - 1) / threads, cosets), dim3(threads), 0, st, vals, lg_npc, ab, dig, prc);
 }
 void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m, const gl_t *prc) {

@@ -106,6 +106,50 @@ P2_HD gl_t poseidon_sbox(gl_t x) {
   return gl_mul(x4, x3);
 }
 
+#if defined(__HIPCC__)
+// ---- ONE Poseidon permutation spread over 12 lanes of a 16-lane group (four permutations per wave) --------------------
+// For the latency-bound tops of Poseidon Merkle trees: one lane per node is 25 000 dependent-issue instructions per level (a lone
+// wave issues one VALU instruction per 5.3-6.1 cycles: ~60 us); here lane i holds state word i, a round is the constant, the
+// S-box (every lane computes it, lane 0 alone keeps it in the partial rounds), 22 ds_bpermute fetches of the other eleven words
+// and this row's dot product with the circulant -- ~140 VALU instructions per round instead of ~850.
+// nb[k - 1] = byte address (lane * 4) of the lane that holds word (i + k) % 12, k = 1..11.
+struct PoseidonCoopLane {
+  uint32_t nb[11];
+  uint32_t i;   // word index of this lane (12..15: idle lanes, they mimic word 0 and nobody reads them)
+};
+__device__ __forceinline__ PoseidonCoopLane poseidon_coop_lane(uint32_t lane) {
+  PoseidonCoopLane c;
+  const uint32_t base = lane & ~15u, i0 = lane & 15u;
+  c.i = i0 < 12 ? i0 : 0;
+#pragma unroll
+  for (int k = 1; k < 12; k++) c.nb[k - 1] = (base + (c.i + k) % 12) * 4;
+  return c;
+}
+__device__ __forceinline__ gl_t poseidon_permute_coop(gl_t x, const gl_t *__restrict__ rc, const PoseidonCoopLane &c) {
+  const uint32_t k0 = POSEIDON_MDS_CIRC[0] + (c.i == 0 ? POSEIDON_MDS_DIAG0 : 0u);
+  gl_t cur = rc[c.i];
+#pragma unroll 1
+  for (int r = 0; r < 30; r++) {
+    const gl_t nxt = rc[12 * (r < 29 ? r + 1 : 29) + c.i];  // next round's constant: in flight under this round's arithmetic
+    x = gl_add(x, cur);
+    cur = nxt;
+    const gl_t sb = poseidon_sbox(x);
+    if (r < 4 || r >= 26 || c.i == 0) x = sb;
+    uint64_t lo = (uint64_t)(uint32_t)x * k0, hi = (x >> 32) * k0;
+#pragma unroll
+    for (int k = 1; k < 12; k++) {
+      const uint32_t vl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)c.nb[k - 1], (int)(uint32_t)x);
+      const uint32_t vh = (uint32_t)__builtin_amdgcn_ds_bpermute((int)c.nb[k - 1], (int)(uint32_t)(x >> 32));
+      lo += (uint64_t)vl * POSEIDON_MDS_CIRC[k];
+      hi += (uint64_t)vh * POSEIDON_MDS_CIRC[k];
+    }
+    const uint64_t l = lo + (hi << 32);
+    x = gl_reduce128(l, (hi >> 32) + (l < lo));
+  }
+  return x;
+}
+#endif
+
 inline void poseidon_permute_host(gl_t st[12], const gl_t rc[360]) {
   for (int r = 0; r < 30; r++) {
     for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], rc[12 * r + i]);

@@ -387,7 +387,8 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
   bool mirrored = false;
   for (size_t l = 1; l < b.level_off.size(); l++) {
     // the rest of the tree in merkle_tail: a few launches of several levels each (Keccak), or one (Poseidon)
-    if (merkle_tail_fuses(hprc(c)) ? (size_t)CL * (m >> 1) <= (size_t)1024 * 64 : m <= tail_nodes()) {
+    const size_t from = merkle_tail_from(hprc(c));
+    if (from ? (size_t)CL * (m >> 1) <= from : m <= tail_nodes()) {
       mirrored = merkle_tail(c->stream, b.dig.p + b.level_off[l - 1], CL, (uint32_t)m, (uint32_t)cap_target, hprc(c), mirror);
       m = cap_target;
       break;

@@ -234,6 +234,7 @@ struct CircuitState {
   DBuf<GateDesc> d_gates;
   DBuf<uint8_t> d_row_gate;   // [n] gate index of every row (from the selector columns)
   DBuf<gl_t> d_gconsts, d_prc; // gate-constant columns [NC - num_selectors][n]; Poseidon round constants
+  DBuf<gl_t> d_prc_hash;       // the same constants in the form the hash kernels take (poseidon_device_constants)
   NttPlan *plan_inv = nullptr, *plan_fwd = nullptr;  // size n: values->coeffs (DIF, w^-1), coeffs->values (DIT)
   std::vector<NttPlan *> fri_plans;                   // DIT plans of the FRI step sizes
   // oracles

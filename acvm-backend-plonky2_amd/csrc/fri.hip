@@ -356,16 +356,16 @@ __global__ __launch_bounds__(256) void pow_kernel(PowState st0, uint32_t pos, ui
   if constexpr (H == 1) {  // Challenger<F, PoseidonHash>: the sponge permutation is Poseidon
 #pragma unroll 1
     for (int r = 0; r < 30; r++) {
-#pragma unroll
-      for (int j = 0; j < 12; j++) st[j] = gl_add(st[j], prc[12 * r + j]);
       if (r < 4 || r >= 26) {
 #pragma unroll
-        for (int j = 0; j < 12; j++) st[j] = poseidon_sbox(st[j]);
-      } else {
-        st[0] = poseidon_sbox(st[0]);
+        for (int j = 0; j < 12; j++) st[j] = poseidon_sbox_nc(gl_add(st[j], prc[12 * r + j]));
+      } else {  // (prc = poseidon_device_constants)
+        st[0] = poseidon_sbox_nc(gl_add(st[0], prc[12 * r]));
       }
       poseidon_mds_dev(st);
     }
+#pragma unroll
+    for (int j = 0; j < 12; j++) st[j] = gl_canon(st[j]);
   } else {
     keccak_permutation12(st);
   }

@@ -138,7 +138,9 @@ P2_HD gl_t gl_add(gl_t a, gl_t b) {
 }
 // (w3 w2 w1 w0) mod p = (w1:w0) + w2 * eps - w3  (2^64 = eps, 2^96 = -1).  With c = carry(w1 + w2):
 // ((w1 + w2 + c) : w0) - (w2 + w3 + c), one wrap at most, then the canonical representative.
-P2_HD gl_t gl_reduce_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+// (_nc: SOME u64 congruent to the value, not necessarily < p -- for intermediates whose only consumers are products and
+// unreduced dot products, which take any u64: three instructions less than the canonical form)
+P2_HD uint64_t gl_reduce_words_nc(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
   uint32_t r0, r1, y0;
   uint64_t cy, k;
   asm("v_add_co_u32 %1, vcc, %6, %7\n\t"          // u1 = w1 + w2, carry c
@@ -154,8 +156,9 @@ P2_HD gl_t gl_reduce_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
       : "=&v"(r0), "=&v"(r1), "=&v"(y0), "=&s"(cy), "=&s"(k)
       : "v"(w0), "v"(w1), "v"(w2), "v"(w3)
       : "vcc", "scc");
-  return gl_canon(gl_join(r0, r1));
+  return gl_join(r0, r1);
 }
+P2_HD gl_t gl_reduce_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) { return gl_canon(gl_reduce_words_nc(w0, w1, w2, w3)); }
 P2_HD gl_t gl_reduce128(uint64_t lo, uint64_t hi) {
   return gl_reduce_words((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
@@ -238,6 +241,20 @@ P2_HD gl_t gl_mul(gl_t a, gl_t b) {
   return gl_reduce128(lo, hi);
 }
 P2_HD gl_t gl_sqr(gl_t a) { return gl_mul(a, a); }
+#if defined(__HIP_DEVICE_COMPILE__) && P2_GL_DEV_ASM
+// a * b for ANY u64 a, b (congruent operands in, congruent u64 out, not canonical)
+__device__ __forceinline__ uint64_t gl_mul_nc(uint64_t a, uint64_t b) {
+  uint64_t lo, hi;
+  gl_mul128(a, b, lo, hi);
+  return gl_reduce_words_nc((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+__device__ __forceinline__ uint64_t gl_reduce128_nc(uint64_t lo, uint64_t hi) {
+  return gl_reduce_words_nc((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+#else
+P2_HD uint64_t gl_mul_nc(uint64_t a, uint64_t b) { return gl_mul(gl_canon(a), gl_canon(b)); }
+P2_HD uint64_t gl_reduce128_nc(uint64_t lo, uint64_t hi) { return gl_reduce128(lo, hi); }
+#endif
 // a * b + c with one reduction: (p-1)^2 + p < 2^128, so the sum is formed unreduced
 P2_HD gl_t gl_mul_add(gl_t a, gl_t b, gl_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)

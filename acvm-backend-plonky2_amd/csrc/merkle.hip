@@ -25,16 +25,16 @@ namespace p2 {
 __device__ __forceinline__ void poseidon_permute_dev(gl_t st[12], const gl_t *__restrict__ prc) {
 #pragma unroll 1
   for (int r = 0; r < 30; r++) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], prc[12 * r + i]);
     if (r < 4 || r >= 26) {
 #pragma unroll
-      for (int i = 0; i < 12; i++) st[i] = poseidon_sbox(st[i]);
-    } else {
-      st[0] = poseidon_sbox(st[0]);
+      for (int i = 0; i < 12; i++) st[i] = poseidon_sbox_nc(gl_add(st[i], prc[12 * r + i]));
+    } else {  // (prc = poseidon_device_constants: words 1..11 of a partial round have nothing to add)
+      st[0] = poseidon_sbox_nc(gl_add(st[0], prc[12 * r]));
     }
     poseidon_mds_dev(st);
   }
+#pragma unroll
+  for (int i = 0; i < 12; i++) st[i] = gl_canon(st[i]);
 }
 // hash_n_to_m_no_pad: overwrite-mode sponge, 8 elements per permutation, first 4 words out
 template <class F>

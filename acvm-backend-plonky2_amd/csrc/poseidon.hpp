@@ -79,7 +79,8 @@ P2_HD void poseidon_mds(gl_t st[12]) {
   for (int i = 0; i < 12; i++) st[i] = r[i];
 }
 #if defined(__HIPCC__)
-// the same linear layer on the device: the MDS entries are < 2^6, so a row is two 64-bit dot products over the
+// the same linear layer on the device (its outputs are congruent u64s, NOT canonical -- gl_add, the S-box and this layer take
+// any u64; poseidon_permute_dev canonicalises the state once after the last round): the MDS entries are < 2^6, so a row is two 64-bit dot products over the
 // 32-bit halves of the state (one v_mad_u64_u32 per term and half) and ONE reduction, instead of 13 128-bit
 // multiply-accumulates: 30 layers x 12 rows make this the bulk of a permutation
 __device__ __forceinline__ void poseidon_mds_dev(gl_t st[12]) {
@@ -95,7 +96,7 @@ __device__ __forceinline__ void poseidon_mds_dev(gl_t st[12]) {
       hi += (v >> 32) * k;
     }
     const uint64_t l = lo + (hi << 32);
-    r[row] = gl_reduce128(l, (hi >> 32) + (l < lo));
+    r[row] = gl_reduce128_nc(l, (hi >> 32) + (l < lo));  // congruent, not canonical: the callers canonicalise once, at the end
   }
 #pragma unroll
   for (int i = 0; i < 12; i++) st[i] = r[i];
@@ -104,6 +105,12 @@ __device__ __forceinline__ void poseidon_mds_dev(gl_t st[12]) {
 P2_HD gl_t poseidon_sbox(gl_t x) {
   gl_t x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x2, x);
   return gl_mul(x4, x3);
+}
+// x^7 as SOME u64 congruent to it: for the permutations whose next step is the MDS layer's unreduced dot products (which take
+// any u64 and end in one canonical reduction) -- the four canonicalisations of the S-box are 6 % of a permutation
+P2_HD uint64_t poseidon_sbox_nc(gl_t x) {
+  const uint64_t x2 = gl_mul_nc(x, x), x4 = gl_mul_nc(x2, x2), x3 = gl_mul_nc(x2, x);
+  return gl_mul_nc(x4, x3);
 }
 
 #if defined(__HIPCC__)
@@ -133,7 +140,7 @@ __device__ __forceinline__ gl_t poseidon_permute_coop(gl_t x, const gl_t *__rest
     const gl_t nxt = rc[12 * (r < 29 ? r + 1 : 29) + c.i];  // next round's constant: in flight under this round's arithmetic
     x = gl_add(x, cur);
     cur = nxt;
-    const gl_t sb = poseidon_sbox(x);
+    const gl_t sb = poseidon_sbox_nc(x);
     if (r < 4 || r >= 26 || c.i == 0) x = sb;
     uint64_t lo = (uint64_t)(uint32_t)x * k0, hi = (x >> 32) * k0;
 #pragma unroll
@@ -144,11 +151,34 @@ __device__ __forceinline__ gl_t poseidon_permute_coop(gl_t x, const gl_t *__rest
       hi += (uint64_t)vh * POSEIDON_MDS_CIRC[k];
     }
     const uint64_t l = lo + (hi << 32);
-    x = gl_reduce128(l, (hi >> 32) + (l < lo));
+    x = gl_reduce128_nc(l, (hi >> 32) + (l < lo));
   }
-  return x;
+  return gl_canon(x);
 }
 #endif
+
+// Round constants for the DEVICE permutations of the hash paths (not the PoseidonGate, whose wires hold every round's S-box
+// inputs as the plain form defines them): in the 22 partial rounds only word 0 meets the S-box, so the constants of words
+// 1..11 commute with the linear layer -- M (s + e) = M s + M e -- and can ride along as a known offset o that is settled in
+// the first full round after them.  out = rc except: partial round r: out[12r] = rc[12r] + o[0], out[12r + 1..11] = 0, then
+// o = M (0, o[1..] + rc[12r + 1..]); round 26: out += o.  Same permutation, 242 modular additions fewer per call for code
+// that skips the zeros (one lane per sponge); code that adds all twelve entries stays correct as it is.
+inline void poseidon_device_constants(const gl_t rc[360], gl_t out[360]) {
+  for (int i = 0; i < 360; i++) out[i] = rc[i];
+  gl_t o[12] = {0};
+  for (int r = 4; r < 26; r++) {
+    gl_t e[12];
+    out[12 * r] = gl_add(o[0], rc[12 * r]);
+    e[0] = 0;
+    for (int i = 1; i < 12; i++) {
+      e[i] = gl_add(o[i], rc[12 * r + i]);
+      out[12 * r + i] = 0;
+    }
+    poseidon_mds(e);
+    for (int i = 0; i < 12; i++) o[i] = e[i];
+  }
+  for (int i = 0; i < 12; i++) out[12 * 26 + i] = gl_add(rc[12 * 26 + i], o[i]);
+}
 
 inline void poseidon_permute_host(gl_t st[12], const gl_t rc[360]) {
   for (int r = 0; r < 30; r++) {

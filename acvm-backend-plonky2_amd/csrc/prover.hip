@@ -356,7 +356,7 @@ size_t tail_nodes() {
 }
 
 // device copy of the Poseidon round constants when the circuit's hasher is PoseidonHash, nullptr for Keccak
-const gl_t *hprc(const p2gpu_circuit *c) { return c->hasher == 1 ? c->d_prc.p : nullptr; }
+const gl_t *hprc(const p2gpu_circuit *c) { return c->hasher == 1 ? c->d_prc_hash.p : nullptr; }
 
 // The transcript sync points of a proof.  Default: hipStreamSynchronize, which spins on the host (lowest latency: the
 // eleven round trips of a lone proof).  Knob "blocking_sync" = 1: record an event created with hipEventBlockingSync and
@@ -1084,7 +1084,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
 void circuit_release(p2gpu_circuit *c) {
   c->tw_fwd.release(); c->tw_inv.release(); c->scale.release(); c->inv_scale.release(); c->d_kis.release();
   c->d_sigmas.release(); c->fri_scale.release(); c->d_gates.release(); c->qconst.release(); c->l0_lde.release();
-  c->d_row_gate.release(); c->d_gconsts.release(); c->d_prc.release(); c->qconst.release();
+  c->d_row_gate.release(); c->d_gconsts.release(); c->d_prc.release(); c->d_prc_hash.release(); c->qconst.release();
   c->cs.release(); c->wires.release(); c->zp.release(); c->quot.release();
   c->wires_vals.release(); c->zp_vals.release(); c->cp.release(); c->rowprod.release(); c->scan_tmp.release();
   c->apow.release(); c->qvals.release(); c->qtmp.release(); c->pw.release(); c->partial.release();
@@ -1493,6 +1493,12 @@ static int circuit_create_one(const uint8_t *blob, size_t len, int device, p2gpu
     if (ngc)
       CK(hipMemcpy(c->d_gconsts.p, constants + (size_t)c->num_selectors * n, 8 * (size_t)ngc * n, hipMemcpyHostToDevice), "copy gconsts");
     CK(hipMemcpy(c->d_prc.p, c->poseidon_rc, sizeof c->poseidon_rc, hipMemcpyHostToDevice), "copy prc");
+    {
+      gl_t hrc[360];
+      poseidon_device_constants(c->poseidon_rc, hrc);
+      CK(c->d_prc_hash.alloc(360), "alloc prc (hash form)");
+      CK(hipMemcpy(c->d_prc_hash.p, hrc, sizeof hrc, hipMemcpyHostToDevice), "copy prc (hash form)");
+    }
   }
   mark("sigma/constant uploads, row->gate");
   if (batch_alloc(c, c->cs, ncs) || batch_alloc(c, c->wires, c->W) || batch_alloc(c, c->zp, nzp) || batch_alloc(c, c->quot, nq)) {

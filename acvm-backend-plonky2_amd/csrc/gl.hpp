@@ -268,6 +268,19 @@ P2_HD gl_t gl_mul_add(gl_t a, gl_t b, gl_t c) {
 #endif
   return gl_reduce128(lo, hi);
 }
+// a * b + c as SOME congruent u64 (a, b any u64 with a * b + c < 2^128: e.g. one of them canonical): for factors of a running
+// product, whose only consumer is the next multiplication
+P2_HD uint64_t gl_mul_add_nc(uint64_t a, uint64_t b, gl_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint64_t lo, hi;
+  gl_mul128(a, b, lo, hi);
+  lo += c;
+  hi += lo < c;
+  return gl_reduce128_nc(lo, hi);
+#else
+  return gl_mul_add(gl_canon(a), gl_canon(b), c);
+#endif
+}
 // multiply by a small constant (< 2^32): the product fits in 96 bits
 P2_HD gl_t gl_mul_small(gl_t a, uint32_t k) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -51,17 +51,18 @@ __global__ __launch_bounds__(256) void zs_chunk_kernel(ZsArgs a) {
   const gl_t bx = gl_mul(beta, x);
   gl_t np[16], dp[16];
   for (uint32_t m = 0; m < a.nchunks; m++) {
-    gl_t pn = 1, pd = 1;
+    // the factors and the running products are only ever multiplied: congruent u64s (gl.hpp _nc), canonical once per chunk
+    uint64_t pn = 1, pd = 1;
     for (uint32_t j = m * a.QF; j < (m + 1) * a.QF && j < a.R; j++) {
       gl_t wv = a.wires[(size_t)j * n + i];
       const gl_t wg = gl_add(wv, gamma);
-      gl_t num = gl_mul_add(bx, a.k_is[j], wg);
-      gl_t den = gl_mul_add(beta, a.sigmas[(size_t)j * n + i], wg);
-      pn = gl_mul(pn, num);
-      pd = gl_mul(pd, den);
+      const uint64_t num = gl_mul_add_nc(bx, a.k_is[j], wg);
+      const uint64_t den = gl_mul_add_nc(beta, a.sigmas[(size_t)j * n + i], wg);
+      pn = gl_mul_nc(pn, num);
+      pd = gl_mul_nc(pd, den);
     }
-    np[m] = pn;
-    dp[m] = pd;
+    np[m] = gl_canon(pn);
+    dp[m] = gl_canon(pd);
   }
   // Montgomery batch inversion of the chunk denominators
   gl_t pre[16];
@@ -215,19 +216,19 @@ __global__ __launch_bounds__(256, P2_QUOT_WAVES) void quotient_kernel(const Quot
     const gl_t bx0 = gl_mul(a.betas[0], x), bx1 = gl_mul(a.betas[1], x);
     const uint32_t t_base = out.t;
     for (uint32_t m = 0; m < a.nchunks; m++) {
-      gl_t n0 = 1, d0 = 1, n1 = 1, d1 = 1;
+      uint64_t n0 = 1, d0 = 1, n1 = 1, d1 = 1;  // running products: congruent u64s, only ever multiplied (gl.hpp _nc)
 #pragma unroll 8
       for (uint32_t j = m * a.QF; j < (m + 1) * a.QF && j < a.R; j++) {
         const gl_t wv = wl[(size_t)j * n];
         const gl_t sg = cs[(size_t)(a.NC + j) * n];
         const gl_t kj = a.k_is[j];
         const gl_t wg0 = gl_add(wv, a.gammas[0]);
-        n0 = gl_mul(n0, gl_mul_add(bx0, kj, wg0));
-        d0 = gl_mul(d0, gl_mul_add(a.betas[0], sg, wg0));
+        n0 = gl_mul_nc(n0, gl_mul_add_nc(bx0, kj, wg0));
+        d0 = gl_mul_nc(d0, gl_mul_add_nc(a.betas[0], sg, wg0));
         if (a.K > 1) {
           const gl_t wg1 = gl_add(wv, a.gammas[1]);
-          n1 = gl_mul(n1, gl_mul_add(bx1, kj, wg1));
-          d1 = gl_mul(d1, gl_mul_add(a.betas[1], sg, wg1));
+          n1 = gl_mul_nc(n1, gl_mul_add_nc(bx1, kj, wg1));
+          d1 = gl_mul_nc(d1, gl_mul_add_nc(a.betas[1], sg, wg1));
         }
       }
       for (uint32_t c = 0; c < a.K; c++) {

@@ -35,6 +35,13 @@ struct BaseOps {
   static P2_HD T add(T a, T b) { return gl_add(a, b); }
   static P2_HD T sub(T a, T b) { return gl_sub(a, b); }
   static P2_HD T mul(T a, T b) { return gl_mul(a, b); }
+  // a product / a seventh power whose ONLY consumers take any u64 congruent to it (Consumer::emit's multiply-accumulate, the
+  // SmallDot rows of the Poseidon linear layer): the canonicalisation is skipped (gl.hpp _nc)
+  static P2_HD T mul_out(T a, T b) { return gl_mul_nc(a, b); }
+  static P2_HD T pow7_out(T x) {
+    const uint64_t x2 = gl_mul_nc(x, x), x4 = gl_mul_nc(x2, x2), x3 = gl_mul_nc(x2, x);
+    return gl_mul_nc(x4, x3);
+  }
   static P2_HD T mul_small(T a, uint32_t k) { return gl_mul_small(a, k); }
   static P2_HD T dbl(T a) { return gl_dbl(a); }
   // acc = acc * 2^bits + v, kept unreduced in 128 bits and reduced once: limb recompositions
@@ -69,6 +76,11 @@ struct ExtOps {
   static P2_HD T add(T a, T b) { return ext_add(a, b); }
   static P2_HD T sub(T a, T b) { return ext_sub(a, b); }
   static P2_HD T mul(T a, T b) { return ext_mul(a, b); }
+  static P2_HD T mul_out(T a, T b) { return ext_mul(a, b); }
+  static P2_HD T pow7_out(T x) {
+    const T x2 = ext_mul(x, x), x4 = ext_mul(x2, x2), x3 = ext_mul(x2, x);
+    return ext_mul(x4, x3);
+  }
   static P2_HD T mul_small(T a, uint32_t k) { return ext_make(gl_mul_small(a.c0, k), gl_mul_small(a.c1, k)); }
   static P2_HD T dbl(T a) { return ext_add(a, a); }
   struct Horner {
@@ -86,7 +98,7 @@ struct ExtOps {
 template <class F>
 P2_HD typename F::T range4(typename F::T v) {  // v (v-1) (v-2) (v-3) = u (u + 2), u = v^2 - 3v: two products
   typename F::T u = F::sub(F::mul(v, v), F::add(F::dbl(v), v));
-  return F::mul(u, F::add(u, F::from(2)));
+  return F::mul_out(u, F::add(u, F::from(2)));  // (every caller hands the result to out.emit)
 }
 template <class F>
 P2_HD typename F::T range_product(typename F::T v, uint32_t base) {
@@ -151,15 +163,11 @@ P2_HD void eval_poseidon_gate(WF W, const gl_t *prc, OUT &out) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-      for (int i = 0; i < 12; i++) {
-        T x2 = F::mul(st[i], st[i]), x4 = F::mul(x2, x2), x3 = F::mul(x2, st[i]);
-        st[i] = F::mul(x4, x3);
-      }
+      for (int i = 0; i < 12; i++) st[i] = F::pow7_out(st[i]);  // consumed by the SmallDot rows below only
     } else {
       const T sb = W(65 + (r - 4));
       out.emit(F::sub(st[0], sb));
-      T x2 = F::mul(sb, sb), x4 = F::mul(x2, x2), x3 = F::mul(x2, sb);
-      st[0] = F::mul(x4, x3);
+      st[0] = F::pow7_out(sb);
     }
     // MDS layer: out[row] = sum_i st[(i + row) % 12] * CIRC[i] + st[row] * DIAG[row]
     T nx[12];

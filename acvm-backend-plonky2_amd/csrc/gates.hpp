@@ -68,6 +68,12 @@ struct BaseOps {
       const uint64_t l = lo + (hi << 32);
       return gl_reduce128(l, (hi >> 32) + (l < lo));
     }
+    // the same sum as SOME congruent u64: for consumers that take one -- the FIRST operand of add / sub (gl_add and gl_sub
+    // stay exact when only their first operand is not canonical), pow7_out, SmallDot::add, out.emit
+    P2_HD T value_out() const {
+      const uint64_t l = lo + (hi << 32);
+      return gl_reduce128_nc(l, (hi >> 32) + (l < lo));
+    }
   };
 };
 struct ExtOps {
@@ -92,6 +98,7 @@ struct ExtOps {
     T acc = ext_make(0, 0);
     P2_HD void add(T v, uint32_t k) { acc = ExtOps::add(acc, mul_small(v, k)); }
     P2_HD T value() const { return acc; }
+    P2_HD T value_out() const { return acc; }
   };
 };
 
@@ -181,7 +188,7 @@ P2_HD void eval_poseidon_gate(WF W, const gl_t *prc, OUT &out) {
 #pragma unroll
 #endif
       for (int i = 1; i < 12; i++) acc.add(st[(i + row) % 12], POSEIDON_MDS_CIRC[i]);
-      nx[row] = acc.value();
+      nx[row] = acc.value_out();  // the next round adds a constant to it / subtracts a wire from it (first operands), or raises it
     }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll

@@ -111,8 +111,8 @@ template <class F>
 P2_HD typename F::T range_product(typename F::T v, uint32_t base) {
   if (base == 4) return range4<F>(v);
   typename F::T p = v;
-  for (uint32_t x = 1; x < base; x++) p = F::mul(p, F::sub(v, F::from(x)));
-  return p;
+  for (uint32_t x = 1; x + 1 < base; x++) p = F::mul(p, F::sub(v, F::from(x)));
+  return base > 1 ? F::mul_out(p, F::sub(v, F::from(base - 1))) : p;  // (the last product goes to out.emit only)
 }
 // RandomAccessGate list fold: the nested multiplexer x + b (y - x), lowest bit innermost (the
 // same expression tree as folding pairs level by level), evaluated depth-first with

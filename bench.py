@@ -287,8 +287,8 @@ def main():
                          "PoseidonGate to the gate set every LDE row evaluates); 0 = the BASELINE parity shape")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="independent proofs in flight per GPU IN THE TIMED REGION (separate circuit handles / HIP streams, "
-                         "one host thread each; measured on MI355X at 2^20 rows, round 2's final code: 1 -> 147-160, 2 -> 181, 3 -> 189, "
-                         "4 -> 183-207, 6 -> 196 proofs/s); 1 = strictly one proof at a time, so ms_per_step is a prove latency.  Capped so that the "
+                         "one host thread each; measured on MI355X at 2^20 rows, round 3's final code, one box: 1 -> 172, 2 -> 201, 3 -> 212, "
+                         "4 -> 213, 6 -> 216, 8 -> 213 proofs/s); 1 = strictly one proof at a time, so ms_per_step is a prove latency.  Capped so that the "
                          "handles fit HBM (2^23 rows: 2, 2^24 rows: 1); the prove latency is measured in its own pass either way")
     ap.add_argument("--pipelined", type=int, default=3,
                     help="N = 1: after the timed region, also measure this many proofs in flight (0 = skip)")

@@ -1959,8 +1959,8 @@ static int prove_host(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, c
   // the last chunk only its own two permutations and the tree remain.
   const double t0 = now_ms();
   static const uint32_t chunk_cols = [] {
-    // rate blocks (17 columns) per upload chunk; the override is for measurements (scratch/chunk_sweep.sh, 2^20 rows:
-    // 2 blocks 8.74 ms lone / 163-171 proofs/s in flight, 3: 8.70 / 174, 4: 8.56 / 160, 6: 8.88 / 154)
+    // rate blocks (17 columns) per upload chunk; the override is for measurements (scratch/chunk_sweep.sh, 2^20 rows, round 3 with the
+    // host scan shipping 80 columns: 2 blocks 6.85-7.2 ms lone / 202-203 proofs/s in flight, 3: 7.75-8.05 / 206, 4: 7.5 / 186, 5: 9.6-10 / 203)
     const char *e = getenv("P2GPU_CHUNK_BLOCKS");
     const int b = e ? atoi(e) : 2;
     return (uint32_t)(17 * (b >= 1 && b <= 64 ? b : 2));

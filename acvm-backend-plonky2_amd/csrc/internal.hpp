@@ -38,6 +38,9 @@ struct NttPlan {
   std::vector<NttPass> passes;
   gl_t *ptw = nullptr;   // device: packed per-round twiddle tables
   size_t table_len = 0;
+  uint32_t *fsync = nullptr;  // device: work-queue state of the fused two-pass kernel (two-pass plans only)
+  int fused = 0;              // 0: one launch per pass; 1 / 2: ntt_fused_kernel (ntt.hip)
+  uint32_t fused_lag = 2;
 };
 // which global cosets a sharded launch covers: local index z <-> global coset first + z * stride
 struct CosetMap {
@@ -45,6 +48,11 @@ struct CosetMap {
 };
 NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse);
 void ntt_plan_destroy(NttPlan *p);
+// mode / lag < 0: leave as is
+void ntt_plan_set_fused(NttPlan *p, int mode, int lag);
+// true once a bounded wait inside the fused two-pass kernel has expired in this process (its output is then
+// garbage): checked at every stream synchronisation of the prover, reported as P2GPU_E_DEVICE
+bool ntt_fused_failed();
 // src [cols][n] (or [cosets][cols][n] when src_per_coset), dst [cosets][cols][n]; stride_cols != 0: the
 // launch covers `cols` columns of a batch that has stride_cols columns per coset (chunked pipelines).
 // scale (DIT only): [cosets][n] multiplied into the input; post: multiplied into the output.

@@ -119,7 +119,7 @@ struct EventProf : Prof {  // per-launch timing with HIP events on the launch st
   bool active = false;
   void begin(const char *k, double by) override {
     // (all launches of the transform kernel are kept so that its average agrees with rocprofv3's)
-    active = c->profile >= 2 || by >= 32e6 || strncmp(k, "ntt_pass_kernel", 15) == 0;
+    active = c->profile >= 2 || by >= 32e6 || strncmp(k, "ntt_", 4) == 0;
     if (!active) return;
     name = k;
     bytes = by;
@@ -363,15 +363,20 @@ const gl_t *hprc(const p2gpu_circuit *c) { return c->hasher == 1 ? c->d_prc_hash
 // sleep on it instead -- a woken thread costs ~10-30 us more per round trip, but a process with several proofs in
 // flight no longer burns one CPU per host thread while the GPU works (4 spinning threads per GPU are 32 CPUs on an
 // 8-GPU node: more than the 16-CPU cgroup quota of the MI355X boxes, where the spinning would throttle the ranks).
+int ntt_health() {
+  if (!ntt_fused_failed()) return 0;
+  set_err("a bounded wait inside ntt_fused_kernel expired (work-queue hand-over between its two passes): results discarded");
+  return P2GPU_E_DEVICE;
+}
 int wait_stream(p2gpu_circuit *c) {
   if (!c->blocking_sync) {
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
+    return ntt_health();
   }
   if (!c->sync_event) HIP_TRY(hipEventCreateWithFlags(&c->sync_event, hipEventBlockingSync | hipEventDisableTiming));
   HIP_TRY(hipEventRecord(c->sync_event, c->stream));
   HIP_TRY(hipEventSynchronize(c->sync_event));
-  return 0;
+  return ntt_health();
 }
 
 int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
@@ -1664,6 +1669,13 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
     // proofs made with the knob off overwrite every column without touching the marks: forget them
     if (c->wire_clean.p) HIP_TRY(hipMemsetAsync(c->wire_clean.p, 0, sizeof(uint32_t) * c->W, c->stream));
   }
+  else if (k == "ntt_fused" || k == "ntt_lag") {
+    // both passes of the 2^d-point transforms in one launch (ntt_fused_kernel): same bytes, measured slower -- off by default
+    const int mode = k == "ntt_fused" ? (int)value : -1, lag = k == "ntt_lag" ? (int)value : -1;
+    ntt_plan_set_fused(c->plan_inv, mode, lag);
+    ntt_plan_set_fused(c->plan_fwd, mode, lag);
+    for (NttPlan *p : c->fri_plans) ntt_plan_set_fused(p, mode, lag);
+  }
   else if (k == "profile") {
     flush_kstats(c);
     c->profile = (int)value;
@@ -2108,7 +2120,7 @@ int p2gpu_ifft_batch(const uint64_t *vals, size_t ncols, unsigned d, uint64_t *c
   ntt_plan_destroy(plan);
   HIP_TRY(e1);
   HIP_TRY(e2);
-  return P2GPU_OK;
+  return ntt_health();
 } P2GPU_CATCH
 
 int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned rate_bits, uint64_t *lde_out) try {
@@ -2134,6 +2146,7 @@ int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned r
   ntt_plan_destroy(plan);
   HIP_TRY(e1);
   HIP_TRY(e2);
+  if (int rc = ntt_health()) return rc;
   for (uint32_t r = 0; r < C; r++)
     for (size_t col = 0; col < ncols; col++)
       for (size_t k = 0; k < n; k++) lde_out[col * C * n + C * k + r] = tmp[((size_t)r * ncols + col) * n + k];

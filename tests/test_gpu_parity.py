@@ -73,6 +73,61 @@ def test_ifft_and_lde_match_oracle(pkg, orc, gpu, d):
     assert np.array_equal(lde, np.stack([orc.coset_lde(r, 3) for r in exp]))
 
 
+_FUSED_STAGE = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import __graft_entry__ as ge
+pkg, orc = ge.load_package(), ge.load_oracle()
+P = 0xFFFFFFFF00000001
+for d, cols in ((13, 8), (14, 11), (16, 9), (17, 19), (19, 9)):
+    rng = np.random.default_rng(1000 + d)
+    v = rng.integers(0, P, size=(cols, 1 << d), dtype=np.uint64)
+    v[0, 0] = P - 1
+    v[cols - 1, :] = 0
+    coeffs = pkg.ifft_batch(v)
+    exp = np.stack([orc.ntt(r, inverse=True) for r in v])
+    assert np.array_equal(coeffs, exp), ("ifft", d)
+    rate = 3 if d <= 17 else 1
+    lde = pkg.lde_batch(exp, rate)
+    assert np.array_equal(lde, np.stack([orc.coset_lde(r, rate) for r in exp])), ("lde", d)
+print("fused-stage-ok")
+"""
+
+
+@pytest.mark.parametrize("mode,lag", [(1, 0), (1, 2), (2, 1)])
+def test_fused_two_pass_transforms(gpu, mode, lag):
+    """P2GPU_NTT_FUSED=1/2 (opt-in, ntt.hip): >= 8 columns of a two-pass size (13 <= d <= 21) take ntt_fused_kernel -- both
+    passes in one launch, tiles handed over through per-XCD work queues.  Ragged column counts (not a multiple of the 8
+    queues), every word against the oracle: a second-pass tile that read before the first pass had landed shows up
+    here.  Own process: the stage-level operators take the mode from the environment when their plan is created."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, P2GPU_NTT_FUSED=str(mode), P2GPU_NTT_LAG=str(lag))
+    r = subprocess.run([sys.executable, "-c", _FUSED_STAGE.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fused-stage-ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("d,mix", [(13, "sha"), (14, "ecdsa")])
+def test_fused_transform_knob_keeps_the_proof(pkg, orc, gpu, d, mix):
+    """Knob "ntt_fused" on a handle: every iNTT / LDE of the proof (wires, Z / partial products, quotient, FRI) through the
+    fused kernel, with structured columns skipped by the queue's column claims -- same bytes as the two-launch path and
+    the oracle, resident and chunked host-witness entry points, toggled between proofs."""
+    import torch
+
+    blob, wires = pkg.make_circuit(d, mix, 31)
+    cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
+    expect, _ = oc.prove(wires)
+    wd = torch.from_numpy(wires.view(np.int64)).cuda()
+    for mode, lag in ((1, 0), (0, 0), (1, 3), (2, 1), (0, 0)):
+        cd.set("ntt_fused", mode)
+        cd.set("ntt_lag", lag)
+        assert cd.prove(wd).to_bytes() == expect, (mode, lag)
+        assert cd.prove(wires).to_bytes() == expect, (mode, lag)
+
+
 @pytest.mark.parametrize("d", [21, 22])
 def test_deep_transforms(pkg, orc, gpu, d):
     """2^21 points: 12 + 9 layers (one strided pass with 64-byte runs); 2^22: 12 + 5 + 5 (two strided

@@ -17,6 +17,7 @@ from .prover import (  # noqa: F401
     ProofWithPublicInputs,
     P2GpuError,
     device_info,
+    peer_access,
     init,
     host_array,
     host_free,

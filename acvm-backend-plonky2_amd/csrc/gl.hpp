@@ -86,8 +86,13 @@ P2_HD gl_t gl_reduce128_c(uint64_t lo, uint64_t hi) {
 // hipcc lowers the portable code to v_lshl_add_u64 / v_cmp_lt_u64 / v_cndmask_b32 triples: 6 VALU per add or
 // sub, 17 per reduction.  Here every wrap of 2^64 (= eps = 2^32 - 1 mod p) is taken from the carry flag the
 // 32-bit add already produced and applied as "x0 -/+= m ; x1 +/-= m & !k" (2 VALU + one s_andn2 on the scalar
-// unit, which does not compete for the vector issue slot): sub 4, add 5, reduction 8 + 3, all canonical in,
-// canonical out.  Carry chains through vcc run back to back like the ones of gl_mul128; a carry an instruction
+// unit, which does not compete for the vector issue slot): sub 4, add 5, reduction 8 + 3, canonical out.
+// Operand contract: canonical in, canonical out -- and gl_add(a, b) / gl_sub(a, b) accept ANY u64 as their FIRST operand a
+// as long as b is canonical: the result is then a u64 CONGRUENT to a +- b (a + b < 2^64 + p wraps at most once and the one
+// correction brings it back below 2^64; a >= p > b never borrows), canonical whenever a is.  The gate evaluator relies on
+// that for congruent words (gl_mul_nc, value_out ...) in the first position, whose consumers again take any u64; b must be
+// < p.  Every other form takes canonical operands unless its comment says otherwise.  p2gpu_field_selftest slots 8-13
+// exercise exactly this with operands in [p, 2^64).  Carry chains through vcc run back to back like the ones of gl_mul128; a carry an instruction
 // leaves in another SGPR pair is consumed by the scalar unit or at least two instructions later.  The scalar
 // mask instructions write SCC: it is in every clobber list (the compiler keeps compares live across the block).
 P2_HD gl_t gl_join(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }

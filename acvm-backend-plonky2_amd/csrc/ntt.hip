@@ -1040,7 +1040,7 @@ void fill_coset_scale(hipStream_t st, gl_t *out, gl_t shift, gl_t wN, uint32_t d
 // ---- self-test of the field primitives (stage-level test operator p2gpu_field_selftest) -------------------
 // a[i], b[i]: arbitrary u64.  Every carry-chain form of gl.hpp / mul_pow2 against the portable code, which is
 // what the host and the oracle run: bad[0] canon, [1] add, [2] sub, [3] reduce128, [4] mul, [5] mul_add,
-// [6] mul_pow2<1..95>, [7] Acc160.
+// [6] mul_pow2<1..95>, [7] Acc160, [8..13] the congruent-word (non-canonical) forms, [14..15] unused.
 __global__ void field_selftest_kernel(const uint64_t *a, const uint64_t *b, uint32_t n, unsigned long long *bad) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1075,6 +1075,28 @@ __global__ void field_selftest_kernel(const uint64_t *a, const uint64_t *b, uint
     const uint64_t l2 = yc * yc, h2 = __umul64hi(yc, yc), l3 = xc * xc, h3 = __umul64hi(xc, xc);
     const gl_t want = gl_add_c(gl_add_c(prod, gl_reduce128_c(l2, h2)), gl_reduce128_c(l3, h3));
     if (acc.value() != want) atomicAdd(&bad[7], 1ULL);
+  }
+  // The congruent-word forms (gl.hpp, round 3): operands ANY u64 -- x, y are used raw, so the edge set's words in [p, 2^64)
+  // reach every branch -- result some u64 congruent to the canonical portable value.  [8] gl_mul_nc, [9] gl_mul_add_nc (one
+  // factor canonical: the product plus the addend stays below 2^128), [10] gl_reduce128_nc, [11] gl_add / [12] gl_sub with a
+  // non-canonical FIRST operand (a congruent word comes out; canonical when both operands are), [13] a chain: congruent words fed back into the congruent forms.
+  if (gl_canon(gl_mul_nc(x, y)) != prod) atomicAdd(&bad[8], 1ULL);
+  {
+    uint64_t lo = plo + xc, hi = phi + (lo < xc);
+    if (gl_canon(gl_mul_add_nc(x, yc, xc)) != gl_reduce128_c(lo, hi)) atomicAdd(&bad[9], 1ULL);
+  }
+  if (gl_canon(gl_reduce128_nc(x, y)) != gl_reduce128_c(x, y)) atomicAdd(&bad[10], 1ULL);
+  if (gl_canon(gl_add(x, yc)) != gl_add_c(xc, yc) || gl_add(xc, yc) != gl_add_c(xc, yc)) atomicAdd(&bad[11], 1ULL);
+  if (gl_canon(gl_sub(x, yc)) != gl_sub_c(xc, yc) || gl_sub(xc, yc) != gl_sub_c(xc, yc)) atomicAdd(&bad[12], 1ULL);
+  {
+    const uint64_t u = gl_mul_nc(x, y), v = gl_mul_add_nc(y, xc, yc);   // congruent to x y and y x + y
+    const uint64_t w = gl_mul_nc(u, v);
+    uint64_t l2 = plo + yc, h2 = phi + (l2 < yc);
+    const gl_t vv = gl_reduce128_c(l2, h2);
+    const uint64_t l3 = prod * vv, h3 = __umul64hi(prod, vv);
+    if (gl_canon(w) != gl_reduce128_c(l3, h3)) atomicAdd(&bad[13], 1ULL);
+    if (gl_canon(gl_add(w, xc)) != gl_add_c(gl_reduce128_c(l3, h3), xc)) atomicAdd(&bad[13], 1ULL);
+    if (gl_canon(gl_sub(w, xc)) != gl_sub_c(gl_reduce128_c(l3, h3), xc)) atomicAdd(&bad[13], 1ULL);
   }
 }
 void field_selftest(hipStream_t st, const uint64_t *a, const uint64_t *b, uint32_t n, unsigned long long *bad) {

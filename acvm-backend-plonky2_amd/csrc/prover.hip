@@ -214,6 +214,7 @@ struct PeerGroup {
   std::vector<hipEvent_t> recv_free, sent;
   std::vector<const void *> send_ptr;
   std::vector<void *> recv_ptr;
+  std::vector<std::vector<uint8_t>> proof_scratch;  // ranks > 0 write their (identical) proof bytes here: kept across proofs
   std::mutex m;
   std::condition_variable cv;
   int waiting = 0;
@@ -273,7 +274,13 @@ int peer_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size_
 // communicator (p2gpu_circuit_set_shard_rccl) it is an ncclAllGather enqueued on the circuit's stream;
 // with a host callback (p2gpu_circuit_set_shard: gloo in the CPU-side tests) the stream is drained and
 // the callback returns when the data is in place.
-int shard_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size_t bytes) {
+// (`profile` = 2 brackets every exchange with HIP events on the rank's stream like a kernel launch: pseudo-kernels
+// "exchange[...]" in p2gpu_kernel_stats, by payload class -- the per-exchange microseconds of a sharded proof)
+static const char *exchange_name(size_t bytes) {
+  return bytes <= 4096 ? "exchange[<=4KB: caps, PoW minima]" : bytes < ((size_t)1 << 20) ? "exchange[<1MB: opening sums, query rows]"
+                                                                                        : "exchange[>=1MB: witness blocks, quotient interpolants]";
+}
+static int shard_allgather_impl(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size_t bytes) {
   if (c->peer) return peer_allgather(c, send_dev, recv_dev, bytes);
   if (c->rccl_comm) {
     const RcclApi &r = rccl();
@@ -290,12 +297,23 @@ int shard_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size
       uint8_t *mine = (uint8_t *)recv_dev + (size_t)q * bytes;
       if ((const void *)mine != send_dev) HIP_TRY(hipMemcpyAsync(mine, send_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
       RCCL_TRY(r.GroupStart());
-      for (int p = 0; p < world; p++) {
+      // a failure inside the group still closes it: an open NCCL group would swallow every later call on this thread
+      ncclResult_t bad = ncclSuccess;
+      const char *what = "";
+      for (int p = 0; p < world && bad == ncclSuccess; p++) {
         if (p == q) continue;
-        RCCL_TRY(r.Send(send_dev, bytes, ncclUint8, p, (ncclComm_t)c->rccl_comm, c->stream));
-        RCCL_TRY(r.Recv((uint8_t *)recv_dev + (size_t)p * bytes, bytes, ncclUint8, p, (ncclComm_t)c->rccl_comm, c->stream));
+        bad = r.Send(send_dev, bytes, ncclUint8, p, (ncclComm_t)c->rccl_comm, c->stream);
+        what = "ncclSend";
+        if (bad != ncclSuccess) break;
+        bad = r.Recv((uint8_t *)recv_dev + (size_t)p * bytes, bytes, ncclUint8, p, (ncclComm_t)c->rccl_comm, c->stream);
+        what = "ncclRecv";
       }
-      RCCL_TRY(r.GroupEnd());
+      const ncclResult_t ge = r.GroupEnd();
+      if (bad != ncclSuccess) {
+        set_err("%s failed inside the grouped exchange: %s", what, r.GetErrorString(bad));
+        return P2GPU_E_DEVICE;
+      }
+      RCCL_TRY(ge);
       return 0;
     }
     RCCL_TRY(r.AllGather(send_dev, recv_dev, bytes, ncclUint8, (ncclComm_t)c->rccl_comm, c->stream));
@@ -308,6 +326,10 @@ int shard_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size
     return P2GPU_E_DEVICE;
   }
   return 0;
+}
+int shard_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size_t bytes) {
+  ProfScope ps(exchange_name(bytes), (double)bytes * (double)(c->shard_world > 0 ? c->shard_world : 1));
+  return shard_allgather_impl(c, send_dev, recv_dev, bytes);
 }
 // does this proof go through the exchange steps?  (world 1 + "shard_exercise": the same code with one
 // rank, which is how the RCCL plumbing is exercised on a single-GPU box)
@@ -1146,6 +1168,7 @@ struct ReleaseHook {
 } g_release_hook;
 
 int g_device = -1;
+std::vector<int> g_peer_access;  // [a * n + b]: see p2gpu_peer_access
 std::vector<int> g_devices;  // p2gpu_init's list; more than one entry: circuit handles are device groups
 
 int ensure_device() {
@@ -1214,17 +1237,35 @@ int p2gpu_init(const int *device_ids, int n_devices) {
       set_err("device id %d out of range (%d devices)", dev, cnt);
       return P2GPU_E_ARG;
     }
+  // direct peer copies over xGMI between the ranks of a device group.  Whether a pair got peer access is RECORDED
+  // (p2gpu_peer_access): without it hipMemcpyPeerAsync still works but stages through host memory, which is a different
+  // machine from the "seven concurrent xGMI transfers" the exchange is designed around -- the caller should know
+  std::vector<int> peer(devs.size() * devs.size(), -1);
   for (size_t a = 0; a < devs.size(); a++)
     for (size_t b = 0; b < devs.size(); b++)
-      if (devs[a] != devs[b]) {  // direct peer copies over xGMI; "already enabled" and "not supported" are not errors here
+      if (devs[a] != devs[b]) {
         (void)hipSetDevice(devs[a]);
-        (void)hipDeviceEnablePeerAccess(devs[b], 0);
+        const hipError_t pe = hipDeviceEnablePeerAccess(devs[b], 0);
         (void)hipGetLastError();
+        peer[a * devs.size() + b] = (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) ? 1 : 0;
       }
   HIP_TRY(hipSetDevice(devs[0]));
   g_device = devs[0];
   g_devices = devs;
+  g_peer_access = peer;
   return P2GPU_OK;
+}
+
+// matrix_out[a * n + b] for the n ids of the last p2gpu_init: 1 = device a reaches device b's memory directly (peer access
+// enabled), 0 = it does not (peer copies are staged through the host), -1 = same device.  Returns n, or < 0.
+int p2gpu_peer_access(int *matrix_out, int cap) {
+  if (int rc = ensure_device()) return rc;
+  const int n = (int)g_devices.size();
+  if (matrix_out) {
+    if (cap < n * n) { set_err("p2gpu_peer_access: room for %d entries, %d needed", cap, n * n); return P2GPU_E_BUFFER; }
+    for (int i = 0; i < n * n; i++) matrix_out[i] = i < (int)g_peer_access.size() ? g_peer_access[i] : -1;
+  }
+  return n;
 }
 
 // Page-locked host memory for the wire matrix (and the proof buffer): hipMemcpyAsync from such a buffer is a true DMA at
@@ -1337,14 +1378,22 @@ int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c)
   PeerGroup *pg = new PeerGroup();
   pg->n = n;
   pg->cs = hs;
-  pg->recv_free.resize(n);
-  pg->sent.resize(n);
+  pg->recv_free.assign(n, nullptr);
+  pg->sent.assign(n, nullptr);
+  pg->proof_scratch.resize(n);
   pg->send_ptr.resize(n);
   pg->recv_ptr.resize(n);
   for (int q = 0; q < n; q++) {
     (void)hipSetDevice(hs[q]->device);
     if (hipEventCreateWithFlags(&pg->recv_free[q], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&pg->sent[q], hipEventDisableTiming) != hipSuccess) {
+      for (int k = 0; k <= q; k++) {  // the events of the ranks before this one (and this rank's first) exist: give them back
+        (void)hipSetDevice(hs[k]->device);
+        if (pg->recv_free[k]) (void)hipEventDestroy(pg->recv_free[k]);
+        if (pg->sent[k]) (void)hipEventDestroy(pg->sent[k]);
+        hs[k]->peer = nullptr;
+      }
+      (void)hipSetDevice(g_device);
       delete pg;
       return drop(P2GPU_E_DEVICE, "hipEventCreate failed");
     }
@@ -1808,12 +1857,13 @@ extern "C++" {
 template <class F>
 static int group_prove(p2gpu_circuit *c, uint8_t *proof_out, size_t *proof_len, p2gpu_timings *tm, F f) {
   const size_t cap = *proof_len;
-  std::vector<std::vector<uint8_t>> scratch(c->group.size());
-  std::vector<size_t> lens(c->group.size(), cap);
+  std::vector<std::vector<uint8_t>> local(c->peer ? 0 : c->group.size() + 1);
+  std::vector<std::vector<uint8_t>> &scratch = c->peer ? c->peer->proof_scratch : local;  // one prove per handle at a time
+  std::vector<size_t> lens(c->group.size() + 1, cap);
   return group_run(c, [&](p2gpu_circuit *m, int q) {
     if (q == 0) return f(m, q, proof_out, proof_len, tm);
-    scratch[q - 1].resize(cap);
-    return f(m, q, scratch[q - 1].data(), &lens[q - 1], (p2gpu_timings *)nullptr);
+    if (scratch[q].size() < cap) scratch[q].resize(cap);
+    return f(m, q, scratch[q].data(), &lens[q], (p2gpu_timings *)nullptr);
   });
 }
 }  // extern "C++"
@@ -2153,19 +2203,19 @@ int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned r
   return P2GPU_OK;
 } P2GPU_CATCH
 
-int p2gpu_field_selftest(const uint64_t *a, const uint64_t *b, size_t n, uint64_t bad_out[8]) try {
+int p2gpu_field_selftest(const uint64_t *a, const uint64_t *b, size_t n, uint64_t bad_out[16]) try {
   if (int rc = ensure_device()) return rc;
   if (!a || !b || !bad_out || n == 0 || n > ((size_t)1 << 28)) return P2GPU_E_ARG;
   Scratch S;
   HIP_TRY(hipStreamCreate(&S.st));
   uint64_t *da = S.alloc<uint64_t>(n), *db = S.alloc<uint64_t>(n);
-  unsigned long long *bad = S.alloc<unsigned long long>(8);
+  unsigned long long *bad = S.alloc<unsigned long long>(16);
   if (!da || !db || !bad) { set_err("hipMalloc failed"); return P2GPU_E_DEVICE; }
   HIP_TRY(hipMemcpyAsync(da, a, 8 * n, hipMemcpyHostToDevice, S.st));
   HIP_TRY(hipMemcpyAsync(db, b, 8 * n, hipMemcpyHostToDevice, S.st));
-  HIP_TRY(hipMemsetAsync(bad, 0, 64, S.st));
+  HIP_TRY(hipMemsetAsync(bad, 0, 128, S.st));
   field_selftest(S.st, da, db, (uint32_t)n, bad);
-  HIP_TRY(hipMemcpyAsync(bad_out, bad, 64, hipMemcpyDeviceToHost, S.st));
+  HIP_TRY(hipMemcpyAsync(bad_out, bad, 128, hipMemcpyDeviceToHost, S.st));
   HIP_TRY(hipStreamSynchronize(S.st));
   return P2GPU_OK;
 } P2GPU_CATCH

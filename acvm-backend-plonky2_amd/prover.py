@@ -111,6 +111,8 @@ def load_library():
     lib.p2gpu_hash_rows.argtypes = [vp, sz, sz, u8p]
     lib.p2gpu_field_selftest.argtypes = [vp, vp, sz, vp]
     lib.p2gpu_device_info.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(sz)]
+    lib.p2gpu_peer_access.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    lib.p2gpu_peer_access.restype = ctypes.c_int
     lib.p2gpu_host_alloc.argtypes = [sz]
     lib.p2gpu_host_alloc.restype = vp
     lib.p2gpu_host_free.argtypes = [vp]
@@ -190,6 +192,18 @@ def device_info():
     mem = ctypes.c_size_t()
     _check(lib.p2gpu_device_info(name, 256, ctypes.byref(cu), ctypes.byref(mem)))
     return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+
+def peer_access():
+    """n x n matrix for the device ids of the last ``init``: 1 = device a reaches device b's memory directly (peer copies
+    over xGMI), 0 = it does not (staged through the host), -1 = the same device (``p2gpu_peer_access``)."""
+    lib = load_library()
+    n = lib.p2gpu_peer_access(None, 0)
+    if n < 0:
+        _check(n)
+    m = (ctypes.c_int * (n * n))()
+    _check(min(0, lib.p2gpu_peer_access(m, n * n)))
+    return [[int(m[a * n + b]) for b in range(n)] for a in range(n)]
 
 
 class ProofWithPublicInputs:
@@ -626,7 +640,7 @@ def field_selftest(a, b):
     x = np.ascontiguousarray(a, dtype=np.uint64)
     y = np.ascontiguousarray(b, dtype=np.uint64)
     assert x.shape == y.shape and x.ndim == 1
-    bad = np.zeros(8, dtype=np.uint64)
+    bad = np.zeros(16, dtype=np.uint64)
     _check(lib.p2gpu_field_selftest(x.ctypes.data, y.ctypes.data, x.size, bad.ctypes.data))
     return bad
 

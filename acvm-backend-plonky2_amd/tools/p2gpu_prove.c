@@ -2,7 +2,7 @@
  * p2gpu-prove -- stand-alone caller of the C ABI (include/p2gpu.h), plain C, no Python:
  *
  *     p2gpu-prove <circuit.blob> <wires.bin> <proof.bin> [public_inputs.bin] [--routed] [--vk <vk.blob>]
- *                 [--reference-format]
+ *                 [--reference-format] [--timing]
  *
  * The counterpart of `plonky2-backend prove -b <acir> -w <witness> -o <proof>`
  * (plonky2-backend/src/argument_parsing.rs:36-41 -> actions/prove_action.rs:27-43) below the
@@ -13,12 +13,22 @@
  * uncompressed ProofWithPublicInputs bytes; --vk also writes the verifier's share of the circuit for
  * p2gpu-verify (the reference's `write_vk`, actions/write_vk_action.rs:65-81); --reference-format
  * writes what the reference's CLI writes instead: hex text of the COMPRESSED proof
- * (prove_action.rs:38-42,75-78).  Exit code 0 = ok, 1 = usage/IO, 2 = library error.
+ * (prove_action.rs:38-42,75-78).  --timing prints one JSON line on stdout with the wall time of every stage of this
+ * process -- reading the inputs, p2gpu_init, p2gpu_circuit_create, the first prove, a second prove on the warm handle --
+ * i.e. what one invocation of the reference's CLI pays, which re-translates and re-builds per call (prove_action.rs:27-43);
+ * bench.py reports it as `cold_process`.  Exit code 0 = ok, 1 = usage/IO, 2 = library error.
  */
 #include "../../include/p2gpu.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+static double now_ms(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 
 static void *slurp(const char *path, size_t *len) {
   FILE *f = fopen(path, "rb");
@@ -37,12 +47,14 @@ static void *slurp(const char *path, size_t *len) {
 }
 
 int main(int argc, char **argv) {
-  int routed = 0, npos = 0, ref_format = 0, sparse = 0;
+  int routed = 0, npos = 0, ref_format = 0, sparse = 0, timing = 0;
+  const double t_start = now_ms();
   unsigned long sp_cols = 0, sp_row = 0;
   const char *pos[4] = {0, 0, 0, 0}, *vk_path = NULL;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--routed")) routed = 1;
     else if (!strcmp(argv[i], "--reference-format")) ref_format = 1;
+    else if (!strcmp(argv[i], "--timing")) timing = 1;
     else if (!strcmp(argv[i], "--sparse") && i + 2 < argc) {
       sparse = 1;
       sp_cols = strtoul(argv[++i], NULL, 10);
@@ -87,8 +99,16 @@ int main(int argc, char **argv) {
       return 1;
     }
   }
+  const double t_read = now_ms();
   p2gpu_circuit *c = NULL;
-  int rc = p2gpu_circuit_create(blob, blob_len, &c);
+  int rc = p2gpu_init(NULL, 0); /* device 0: HIP runtime start-up + code-object load happen here and in the first launches */
+  if (rc) {
+    fprintf(stderr, "p2gpu_init: %d: %s\n", rc, p2gpu_last_error());
+    return 2;
+  }
+  const double t_init = now_ms();
+  rc = p2gpu_circuit_create(blob, blob_len, &c);
+  const double t_create = now_ms();
   if (rc) {
     fprintf(stderr, "p2gpu_circuit_create: %d: %s\n", rc, p2gpu_last_error());
     return 2;
@@ -123,6 +143,17 @@ int main(int argc, char **argv) {
     p2gpu_circuit_destroy(c);
     return 2;
   }
+  const double t_prove = now_ms();
+  double warm_ms = -1;
+  if (timing && !sparse && !routed) { /* the same call again on the warm handle: what a resident service pays per proof */
+    size_t len2 = cap;
+    uint8_t *proof2 = malloc(cap);
+    p2gpu_timings t2;
+    const double w0 = now_ms();
+    if (proof2 && p2gpu_prove(c, wires, pis, (uint32_t)(pi_len / 8), proof2, &len2, &t2) == 0) warm_ms = now_ms() - w0;
+    free(proof2);
+  }
+  const double t_warm = now_ms();
   FILE *f = fopen(pos[2], "wb");
   if (!f) {
     fprintf(stderr, "cannot write %s\n", pos[2]);
@@ -147,7 +178,14 @@ int main(int argc, char **argv) {
   fclose(f);
   fprintf(stderr, "proof: %zu bytes; wires %.2f ms, zs %.2f ms, quotient %.2f ms, openings %.2f ms, fri %.2f ms, h2d %.2f ms\n", len,
           t.wires_commit_ms, t.zs_commit_ms, t.quotient_ms, t.openings_ms, t.fri_ms, t.h2d_ms);
+  const double t_write = now_ms();
   p2gpu_circuit_destroy(c);
+  if (timing)
+    printf("{\"read_inputs_ms\": %.3f, \"p2gpu_init_ms\": %.3f, \"circuit_create_ms\": %.3f, \"first_prove_ms\": %.3f, "
+           "\"second_prove_ms\": %.3f, \"write_proof_ms\": %.3f, \"destroy_ms\": %.3f, \"process_ms\": %.3f, "
+           "\"cold_process_ms\": %.3f, \"h2d_ms\": %.3f, \"proof_bytes\": %zu}\n",
+           t_read - t_start, t_init - t_read, t_create - t_init, t_prove - t_create, warm_ms, t_write - t_warm, now_ms() - t_write,
+           now_ms() - t_start, t_prove - t_read, t.h2d_ms, len);
   free(proof);
   free(blob);
   free(wires);

@@ -100,3 +100,40 @@ def test_partition_and_ownership(pkg):
         assert lib.p2gpu_shard_assemble_cap(w, 3, 4, g.ctypes.data, out.ctypes.data) == 0
         assert out.tobytes() == full
     assert lib.p2gpu_shard_assemble_cap(3, 3, 4, g.ctypes.data, out.ctypes.data) != 0  # 8 cosets over 3 ranks
+
+
+def _bench(*argv, env=None):
+    import subprocess
+
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(OMP_NUM_THREADS="2", **(env or {}))
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=600, env=e)
+
+
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`bench.py --gpus 2` outside torchrun starts two ranks itself (the flag used to be parsed and ignored).
+    --dry --backend gloo runs the rank plumbing only -- rendezvous, barrier, the max-over-ranks reduction -- with no GPU."""
+    import json
+
+    r = _bench("--gpus", "2", "--backend", "gloo", "--dry")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks"] == [0, 1] and line["launched_by"] == "bench.py"
+    assert line["max_over_ranks_s"] >= 0.02   # rank 1 sleeps 20 ms: the reduction really took the MAX over both ranks
+    # one rank, no launcher
+    r1 = _bench("--dry")
+    assert r1.returncode == 0 and json.loads(r1.stdout.splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """On a box with fewer devices than --gpus asks for the bench fails loudly -- exit code 2, no JSON line -- instead of
+    printing a line with a smaller n_gpus (this container has no GPU at all; the GPU boxes of the test pool have one)."""
+    import torch
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _bench("--gpus", str(have + 1 if have else 2))
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "HIP device" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+    # a rank whose torchrun world disagrees with --gpus refuses as well (the line's n_gpus must be the N asked for)
+    r2 = _bench("--gpus", "4", "--dry", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+    assert r2.returncode == 2 and "WORLD_SIZE=2" in r2.stderr

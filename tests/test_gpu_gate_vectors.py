@@ -21,6 +21,7 @@ from gate_wires import (G_COMPARISON, G_U32_ADD_MANY, G_U32_ARITHMETIC, G_U32_RA
 pytestmark = pytest.mark.gpu
 G_NOOP = 0
 E_UNSATISFIED = -5
+E_VERIFY = -9
 W = 234
 
 
@@ -37,14 +38,16 @@ def _u32s(rng, n):
     return [int(x) for x in rng.integers(0, 1 << 32, size=n, dtype=np.uint64)]
 
 
-def one_gate_circuit(pkg, kind, params, degree, rows, d=3):
+def one_gate_circuit(pkg, kind, params, degree, rows, d=3, consts=None):
     """2^d rows: `rows` (wire vectors) under the gate, the rest NoopGate; no copy constraints, no public inputs.
-    gates sorted by (degree, id) like CommonCircuitData.gates: Noop (degree 0) first."""
+    gates sorted by (degree, id) like CommonCircuitData.gates: Noop (degree 0) first.  consts: [num_constants][n] gate
+    constants per row (ConstantGate, ArithmeticGate, RandomAccessGate's extra constants)."""
     n = 1 << d
     assert len(rows) <= n
-    gates = [(G_NOOP, (), 0, 0), (kind, tuple(params), degree, 0)]
+    rc = np.zeros((0, n), dtype=np.uint64) if consts is None else np.ascontiguousarray(consts, dtype=np.uint64)
+    gates = [(G_NOOP, (), 0, 0), (kind, tuple(params), degree, rc.shape[0])]
     row_gate = [1] * len(rows) + [0] * (n - len(rows))
-    blob = pkg.build_blob(d, gates, row_gate, np.zeros((0, n), dtype=np.uint64), np.zeros((0, 4), dtype=np.uint32))
+    blob = pkg.build_blob(d, gates, row_gate, rc, np.zeros((0, 4), dtype=np.uint32))
     wires = np.zeros((W, n), dtype=np.uint64)
     for r, w in enumerate(rows):
         assert len(w) <= W and all(0 <= int(v) < P for v in w)
@@ -76,13 +79,13 @@ def expect_unsatisfied(pkg, orc, blob, wires):
         # the same witness with the host-side self-check off: the device evaluator's quotient does not vanish on H, so
         # the proof that comes out is rejected by both verifiers (upstream's prover would have panicked in trim_to_len)
         cd.set("self_check", 0)
-        try:
-            bad = cd.prove(wires).to_bytes()
-        except pkg.P2GpuError:
-            return
+        # (no try / except around this prove: with the self-check off the only acceptable outcomes are proof bytes that the
+        # verifiers then reject -- a device fault or any other error code here is a FAILURE, not a rejection)
+        bad = cd.prove(wires).to_bytes()
         assert not oc.verify(bad)
-        with pytest.raises(pkg.P2GpuError):
+        with pytest.raises(pkg.P2GpuError) as ev:
             cd.verify(bad)
+        assert ev.value.code == E_VERIFY, ev.value
     finally:
         cd.close()
         oc.close()
@@ -180,3 +183,51 @@ def test_comparison_vectors_on_gpu(pkg, orc, gpu):
     bad[2] ^= 1                              # wrong result bool (comparison.rs:700-743 negative)
     blob, wires = one_gate_circuit(pkg, G_COMPARISON, [nb, nc], 4, [rows[0], bad])
     expect_unsatisfied(pkg, orc, blob, wires)
+
+
+# ---- every gate kind on edge words: 0, 1, 2^32 - 1, 2^32, p - 1 ... ---------------------------------------------------------
+# The device evaluator keeps some intermediates as congruent, not canonical, words (gl.hpp _nc forms, round 3); gate rows
+# whose wires sit on the boundaries of the field and of the 32-bit limbs push its carry chains where random witnesses never
+# go.  The rows do not satisfy their gates: with the self-check off both provers still emit bytes, which must be equal
+# (the quotient's coefficients are what they are), and the verifiers must reject them.  Model: arithmetic_u32.rs:572-605.
+EDGE = [0, 1, 2, 3, (1 << 32) - 2, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, 1 << 63, P - (1 << 32), P - (1 << 32) + 1, P - 2, P - 1]
+KINDS = [  # (kind, params, degree, num_constants): include/p2gpu.h "Gate kinds"
+    (1, (2,), 1, 2), (3, (20,), 3, 2), (4, (2, 32), 2, 0), (4, (4, 16), 4, 0), (5, (2, 4, 2), 4, 2),
+    (G_U32_ARITHMETIC, (6,), 4, 0), (G_U32_ADD_MANY, (5, 4), 4, 0), (G_U32_SUBTRACTION, (11,), 4, 0), (G_U32_RANGE_CHECK, (8,), 4, 0),
+    (G_COMPARISON, (32, 16), 4, 0),
+]
+
+
+@pytest.mark.parametrize("kind,params,degree,nconst", KINDS)
+def test_gate_rows_on_edge_words_match_the_oracle(pkg, orc, gpu, kind, params, degree, nconst):
+    rng = np.random.default_rng(100 + kind + len(params))
+    n = 8
+    rows = []
+    for r in range(n - 1):
+        if r == 0:
+            w = [P - 1] * W
+        elif r == 1:
+            w = [(1 << 32) - 1] * W
+        elif r == 2:
+            w = [0] * W
+        else:
+            w = [EDGE[int(i)] for i in rng.integers(0, len(EDGE), size=W)]
+        rows.append(w)
+    consts = np.array([[EDGE[int(i)] for i in rng.integers(0, len(EDGE), size=n)] for _ in range(nconst)], dtype=np.uint64).reshape(nconst, n)
+    blob, wires = one_gate_circuit(pkg, kind, params, degree, rows, consts=consts if nconst else None)
+    cd, oc = pkg.CircuitData(blob), orc.OracleCircuit(blob)
+    try:
+        cd.set("self_check", 0)
+        got = cd.prove(wires).to_bytes()
+        want, _ = oc.prove(wires)
+        assert got == want, "GPU bytes differ from the oracle's on edge-word gate rows"
+        assert not oc.verify(got)
+        with pytest.raises(pkg.P2GpuError):
+            cd.verify(got)
+        cd.set("self_check", 1)
+        with pytest.raises(pkg.P2GpuError) as e:
+            cd.prove(wires)
+        assert e.value.code == E_UNSATISFIED
+    finally:
+        cd.close()
+        oc.close()

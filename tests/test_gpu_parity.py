@@ -55,7 +55,10 @@ def test_field_primitives_match_portable_code(pkg, gpu):
     a = np.concatenate([a, ra, np.repeat(edge, 64)])
     b = np.concatenate([b, rb, rng.integers(0, 1 << 64, size=64 * edge.size, dtype=np.uint64)])
     bad = pkg.field_selftest(a, b)
-    assert not bad.any(), dict(zip("canon add sub reduce128 mul mul_add mul_pow2 acc160".split(), bad.tolist()))
+    # slots 8-13: the congruent-word forms of round 3 (gl_mul_nc, gl_mul_add_nc, gl_reduce128_nc, gl_add / gl_sub with a first
+    # operand in [p, 2^64), chains of them) -- the edge set and the random words above hand them operands >= p directly,
+    # which a proof reaches with probability 2^-32 per operation
+    assert not bad.any(), dict(zip("canon add sub reduce128 mul mul_add mul_pow2 acc160 mul_nc mul_add_nc reduce128_nc add_nc sub_nc chain_nc - -".split(), bad.tolist()))
 
 
 @pytest.mark.parametrize("d", [0, 1, 2, 5, 8, 11, 12, 13, 16])
@@ -943,3 +946,73 @@ def test_measurement_switches_keep_the_bytes(pkg, gpu, env):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
     assert r.returncode == 0, r.stderr[-2000:]
     assert ("DIGEST " + g["proof_sha256"]) in r.stdout, r.stdout[-500:]
+
+
+def test_seeded_differential_fuzz(pkg, orc, gpu):
+    """scratch/fuzz_parity.py as a bounded, seeded test: random (degree, gate mix, seed, public inputs,
+    width), random structure of the unused wire columns (zeroed, extra rows, stray values), random knobs toggled between
+    proofs on one handle (zero_columns / virtual_columns / ntt_fused), all four entry points (host matrix, resident, routed,
+    sparse with a random split): every proof byte-equal to the oracle's; verifier and compress / decompress round trip."""
+    import time
+
+    import torch
+
+    rng = np.random.default_rng(20260930)
+    t0, done = time.time(), 0
+    for it in range(14):
+        if time.time() - t0 > 25 and done >= 6:
+            break
+        d = int(rng.integers(5, 13))
+        mix = ["arith", "sha", "ecdsa"][int(rng.integers(0, 3))]
+        seed = int(rng.integers(1, 1 << 30))
+        npi = int(rng.choice([0, 0, 1, 4, 9, 17]))
+        nw = int(rng.choice([234, 234, 135]))
+        routed_only = bool(rng.integers(0, 2))
+        if nw == 135 and mix == "ecdsa":
+            mix = "sha"   # the ECC gates need the wide config
+        out = pkg.make_circuit(d, mix, seed, num_public_inputs=npi, num_wires=nw, pi_row_routed_only=routed_only)
+        blob, wires = out[0], out[1]
+        pis = out[2] if npi else ()
+        oc, cd = orc.OracleCircuit(blob), pkg.CircuitData(blob)
+        W, n = nw, 1 << d
+        try:
+            for rnd in range(2):
+                w = wires.copy().reshape(W, n)
+                mutated = rnd > 0
+                if mutated:  # perturb the structure of random columns (the witness may stop satisfying the circuit: bytes still comparable)
+                    for c_ in rng.integers(0, W, size=int(rng.integers(1, 6))):
+                        k = int(rng.integers(0, 4))
+                        if k == 0:
+                            w[c_, :] = 0
+                        elif k == 1:
+                            w[c_, int(rng.integers(0, n))] = int(rng.integers(1, 1 << 62))
+                        elif k == 2:
+                            w[c_, :] = 0
+                            w[c_, int(rng.integers(0, n))] = 5
+                        else:
+                            w[c_, rng.integers(0, n, size=3)] = 9
+                w = np.ascontiguousarray(w)
+                cd.set("self_check", 0 if mutated else 1)
+                cd.set("zero_columns", int(rng.integers(0, 4) != 0))
+                cd.set("virtual_columns", int(rng.integers(0, 3) != 0))
+                cd.set("ntt_fused", int(rng.integers(0, 3)))
+                cd.set("ntt_lag", int(rng.integers(0, 4)))
+                expect, _ = oc.prove(w, public_inputs=pis)
+                tag = (it, rnd, d, mix, seed, npi, nw, routed_only)
+                assert cd.prove(w, public_inputs=pis).to_bytes() == expect, ("host",) + tag
+                assert cd.prove(torch.from_numpy(w.view(np.int64)).cuda(), public_inputs=pis).to_bytes() == expect, ("dev",) + tag
+                if routed_only and not mutated:
+                    assert cd.prove_routed(w[:80], public_inputs=pis).to_bytes() == expect, ("routed",) + tag
+                row = int(rng.integers(0, n))
+                dense = np.nonzero(np.delete(w, row, axis=1).any(axis=1))[0]
+                lo = int(dense.max()) + 1 if dense.size else 0
+                ncols = int(rng.integers(lo, W + 1))
+                assert cd.prove_sparse(w, ncols, row, public_inputs=pis).to_bytes() == expect, ("sparse",) + tag
+                if not mutated:
+                    cd.verify(expect)
+                    assert cd.decompress(cd.compress(expect)).to_bytes() == expect
+        finally:
+            cd.close()
+            oc.close()
+        done += 1
+    assert done >= 6

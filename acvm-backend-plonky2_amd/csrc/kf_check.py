@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
-"""Safety net of the fixed-register Keccak kernels (keccak.hpp P2_KF_*): the sponge state lives in v[P2_KF_BASE ...) for the
-whole kernel, so NOTHING hipcc generates outside the asm blocks may name a register at or above P2_KF_BASE, and the kernels
-must not spill.  Compiles merkle.hip to assembly and checks every *_kf_kernel.  `make kf-check` (part of `make`)."""
+"""Safety net of the fixed-register Keccak kernels (keccak.hpp P2_KF_*): the sponge state lives in v[P2_KF_BASE ... P2_KF_TOP)
+for the whole kernel, so NOTHING hipcc generates outside the asm blocks may name a register at or above P2_KF_BASE, the
+kernels must not spill, and the kernel descriptor must reserve the registers up to P2_KF_TOP.
+
+    kf_check.py [HIPCC [ARCH [HIPFLAGS...]]]
+
+`make` passes its own $(HIPCC), $(ARCH) and $(HIPFLAGS), so the assembly checked here is the assembly of the objects that were
+just linked (the flags that only make sense for an object file are dropped).  A function's body runs to its `.Lfunc_end` /
+`.size` line, not to the first `s_endpgm`: an early-exit `s_endpgm` must not leave the rest of the body unchecked."""
 import os
 import re
 import subprocess
@@ -9,20 +15,27 @@ import sys
 import tempfile
 
 here = os.path.dirname(os.path.abspath(__file__))
-base = int(re.search(r"#define P2_KF_BASE (\d+)", open(os.path.join(here, "keccak_fixed.inc")).read()).group(1))
+inc = open(os.path.join(here, "keccak_fixed.inc")).read()
+base = int(re.search(r"#define P2_KF_BASE (\d+)", inc).group(1))
+top = int(re.search(r"#define P2_KF_TOP (\d+)", inc).group(1))
+hipcc = sys.argv[1] if len(sys.argv) > 1 else "hipcc"
+arch = sys.argv[2] if len(sys.argv) > 2 else "gfx950"
+flags = [f for f in sys.argv[3:] if f not in ("-fPIC", "-c") and not f.startswith("--offload-arch")] or ["-O3", "-std=c++17", "-Wno-pass-failed", "-Wno-inline-asm"]
 with tempfile.NamedTemporaryFile(suffix=".s") as f:
-    subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-pass-failed", "-Wno-inline-asm", "--cuda-device-only", "-S",
-                    os.path.join(here, "merkle.hip"), "-o", f.name], check=True, capture_output=True)
+    subprocess.run([hipcc] + flags + [f"--offload-arch={arch}", "--cuda-device-only", "-S", os.path.join(here, "merkle.hip"), "-o", f.name],
+                   check=True, capture_output=True)
     lines = [l.strip() for l in open(f.name)]
 bad = 0
 names = [l[:-1].split(":")[0] for l in lines if re.match(r"^_Z\w*kf_kernel\w*:", l)]
 assert names, "no *_kf_kernel found"
 for name in names:
-    i = lines.index(name + ":") if name + ":" in lines else [k for k, l in enumerate(lines) if l.startswith(name + ":")][0]
-    inasm, mx = False, 0
-    for l in lines[i:]:
+    i = [k for k, l in enumerate(lines) if l.startswith(name + ":")][0]
+    ends = [k for k in range(i, len(lines)) if re.match(r"^\.Lfunc_end\d+:", lines[k]) or lines[k].startswith(".size\t" + name + ",") or lines[k].startswith(".size " + name + ",")]
+    assert ends, f"no end marker for {name}"
+    inasm, mx, endpgm = False, 0, 0
+    for l in lines[i:ends[0]]:
         if l.startswith("s_endpgm"):
-            break
+            endpgm += 1
         if "ASMSTART" in l:
             inasm = True
         elif "ASMEND" in l:
@@ -32,7 +45,21 @@ for name in names:
             if regs:
                 mx = max(mx, max(regs))
     scratch = [int(m.group(1)) for l in lines if (m := re.match(r"\.set " + re.escape(name) + r"\.private_seg_size, (\d+)", l))]
-    ok = mx < base and (not scratch or scratch[0] == 0)
-    print(f"{name[:60]:60s} compiler registers up to v{mx} (state from v{base}), scratch {scratch[0] if scratch else '?'} B: {'ok' if ok else 'VIOLATION'}")
+    # the descriptor's register count: the block clobbers v[BASE, TOP) -- the allocation must cover them
+    nfree = None
+    k0 = [k for k, l in enumerate(lines) if l.startswith(".amdhsa_kernel " + name)]
+    if k0:
+        for l in lines[k0[0]:k0[0] + 80]:
+            m = re.match(r"\.amdhsa_next_free_vgpr\s+(\S+)", l)
+            if m:
+                try:
+                    nfree = int(m.group(1))
+                except ValueError:   # symbolic: resolve through the .set lines
+                    sym = [int(mm.group(1)) for ll in lines if (mm := re.match(r"\.set " + re.escape(name) + r"\.num_vgpr, (\d+)", ll))]
+                    nfree = sym[0] if sym else None
+                break
+    ok = mx < base and (not scratch or scratch[0] == 0) and endpgm >= 1 and (nfree is None or nfree >= top)
+    print(f"{name[:60]:60s} compiler registers up to v{mx} (state v{base}..v{top - 1}), scratch {scratch[0] if scratch else '?'} B, "
+          f"next_free_vgpr {nfree}, s_endpgm x{endpgm}: {'ok' if ok else 'VIOLATION'}")
     bad += not ok
 sys.exit(1 if bad else 0)

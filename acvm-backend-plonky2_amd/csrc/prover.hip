@@ -1340,6 +1340,21 @@ static int group_run(p2gpu_circuit *c, F f) {
 }
 }  // extern "C++"
 
+// A plain (un-sharded) handle on ONE device of the p2gpu_init list, whatever the length of that list: with several ids
+// p2gpu_circuit_create makes device groups (one proof over all of them); this is the other half of BASELINE's metric from the
+// same process -- replicas, one or more independent handles per GPU, each driven from its own host thread.
+int p2gpu_circuit_create_on(const uint8_t *blob, size_t len, int device_id, p2gpu_circuit **out_c) try {
+  if (!blob || !out_c) return P2GPU_E_ARG;
+  if (int rc = ensure_device()) return rc;
+  if (std::find(g_devices.begin(), g_devices.end(), device_id) == g_devices.end()) {
+    set_err("p2gpu_circuit_create_on: device %d is not in the list given to p2gpu_init", device_id);
+    return P2GPU_E_ARG;
+  }
+  const int rc = circuit_create_one(blob, len, device_id, out_c);
+  (void)hipSetDevice(g_device);
+  return rc;
+} P2GPU_CATCH
+
 int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out_c) try {
   if (!blob || !out_c) return P2GPU_E_ARG;
   if (int rc = ensure_device()) return rc;

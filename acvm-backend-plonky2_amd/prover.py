@@ -112,6 +112,7 @@ def load_library():
     lib.p2gpu_field_selftest.argtypes = [vp, vp, sz, vp]
     lib.p2gpu_device_info.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(sz)]
     lib.p2gpu_peer_access.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    lib.p2gpu_circuit_create_on.argtypes = [u8p, sz, ctypes.c_int, ctypes.POINTER(vp)]
     lib.p2gpu_peer_access.restype = ctypes.c_int
     lib.p2gpu_host_alloc.argtypes = [sz]
     lib.p2gpu_host_alloc.restype = vp
@@ -226,7 +227,9 @@ class ProofWithPublicInputs:
 class CircuitData:
     """Prover-side circuit handle (device-resident constants/sigmas oracle, root tables)."""
 
-    def __init__(self, blob):
+    def __init__(self, blob, device=None):
+        """device: None = what ``init`` selected (several ids: a device group, every proof sharded over them); an id of that
+        list = a plain handle on that one device (``p2gpu_circuit_create_on``: replicas across GPUs from one process)."""
         lib = load_library()
         self._lib = lib
         self._blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
@@ -238,7 +241,10 @@ class CircuitData:
         self.cap_height = int(hdr[10])
         self.num_public_inputs = int(hdr[24])
         self._h = ctypes.c_void_p()
-        _check(lib.p2gpu_circuit_create(self._blob.ctypes.data, self._blob.nbytes, ctypes.byref(self._h)))
+        if device is None:
+            _check(lib.p2gpu_circuit_create(self._blob.ctypes.data, self._blob.nbytes, ctypes.byref(self._h)))
+        else:
+            _check(lib.p2gpu_circuit_create_on(self._blob.ctypes.data, self._blob.nbytes, int(device), ctypes.byref(self._h)))
         self._bound = lib.p2gpu_proof_size_bound(self._h)
 
     @classmethod

@@ -376,6 +376,31 @@ def group_probe(pkg, args, group, blob, wires, pis):
            "exchanges": exchange_stats(st, 2), "proof_bytes": len(ref),
            "transport": "hipMemcpyPeerAsync between the ranks' streams, one host thread per rank inside p2gpu_prove_dev"}
     cd.close()
+    # ... and replicas from the same single process: plain handles on named devices (p2gpu_circuit_create_on), two per device
+    # entry of the list, one host thread each -- the throughput half of the metric without a process per GPU
+    import threading
+    per = 2
+    hs = [(pkg.CircuitData(blob, device=dev), dev) for dev in group for _ in range(per)]
+    wdev = {dev: torch.from_numpy(wires.view(np.int64)).to(f"cuda:{dev}") for dev in set(group)}
+    n_each = max(4, args.sharded_steps * 2)
+
+    def work(h, dev, n):
+        for _ in range(n):
+            h.prove(wdev[dev], public_inputs=pis)
+    for n in (2, n_each):   # warm-up, then timed
+        th = [threading.Thread(target=work, args=(h, dev, n)) for h, dev in hs]
+        for dev in set(group):
+            torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+    out["one_process_replicas"] = {"proofs_per_sec": len(hs) * n_each / dt, "handles": len(hs), "per_device_entry": per, "proofs": len(hs) * n_each,
+                                   "entry_point": "p2gpu_circuit_create_on + p2gpu_prove_dev from one host thread per handle"}
+    for h, _ in hs:
+        h.close()
     return out
 
 

@@ -112,6 +112,10 @@ void *p2gpu_host_alloc(size_t bytes);
 void p2gpu_host_free(void *p);
 
 int p2gpu_circuit_create(const uint8_t *blob, size_t len, p2gpu_circuit **out);
+/* The same on ONE named device of the p2gpu_init list -- a plain handle even when the list has several ids (then
+ * p2gpu_circuit_create makes device groups): replicas across the GPUs of a node from one process, one host thread per handle.
+ * (Counterpart: the same `circuit_data.prove` call, prove_action.rs:96, issued once per device.) */
+int p2gpu_circuit_create_on(const uint8_t *blob, size_t len, int device_id, p2gpu_circuit **out);
 void p2gpu_circuit_destroy(p2gpu_circuit *c);
 /* bytes of one digest of this circuit's hasher: 25 (KeccakHash<25>) or 32 (PoseidonHash) */
 int p2gpu_circuit_hash_bytes(const p2gpu_circuit *c);

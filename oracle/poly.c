@@ -123,10 +123,20 @@ void coset_intt(gl_t *a, unsigned lg, gl_t shift) {
 /* Large buffers (the LDE of a batch is gigabytes) on transparent huge pages where the host allows it ("madvise" mode):
  * with 4 KB pages the first touch of ~4 GB per proof is a million page faults taken by every OpenMP thread at once, and
  * on a 128-core host that -- not arithmetic -- was most of the oracle's wall time. */
+static void big_malloc_failed(size_t bytes) {
+  /* the oracle is a checker: one that cannot hold its buffers cannot check anything -- stop loudly instead of handing the
+   * callers (none of which tests for NULL) a pointer to write through */
+  fprintf(stderr, "oracle: cannot allocate %zu bytes\n", bytes);
+  abort();
+}
 void *big_malloc(size_t bytes) {
-  if (bytes < ((size_t)4 << 20)) return malloc(bytes);
+  if (bytes < ((size_t)4 << 20)) {
+    void *q = malloc(bytes ? bytes : 1);
+    if (!q) big_malloc_failed(bytes);
+    return q;
+  }
   void *p = NULL;
-  if (posix_memalign(&p, (size_t)2 << 20, (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1))) return NULL;
+  if (posix_memalign(&p, (size_t)2 << 20, (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1)) || !p) big_malloc_failed(bytes);
 #ifdef MADV_HUGEPAGE
   (void)madvise(p, bytes, MADV_HUGEPAGE);
 #endif

@@ -881,7 +881,27 @@ def test_single_process_device_group(pkg, orc, gpu, world):
             assert cd.prove(wires, public_inputs=pis).to_bytes() == want
             with pytest.raises(pkg.P2GpuError):
                 cd.set_shard(0, 1)       # the sharding of a group is fixed
+            # the same process can still make PLAIN handles on a named device of the list (p2gpu_circuit_create_on): replicas
+            # next to the group, each proving whole proofs from its own thread
+            import threading
+            plain = [pkg.CircuitData(blob, device=0) for _ in range(2)]
+            got = [None, None]
+
+            def work(i):
+                got[i] = plain[i].prove(wires, public_inputs=pis).to_bytes()
+            th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+            for t in th:
+                t.start()
+            assert cd.prove(wd, public_inputs=pis).to_bytes() == want    # the group proves while the replicas do
+            for t in th:
+                t.join()
+            assert got == [want, want]
+            with pytest.raises(pkg.P2GpuError):
+                pkg.CircuitData(blob, device=5)    # not in the init list
+            for h in plain:
+                h.close()
             cd.close()
+        assert pkg.peer_access() == [[-1] * world for _ in range(world)]   # every id is device 0 here: no pair to enable
     finally:
         pkg.init([0])
     # back to one device: ordinary handles again

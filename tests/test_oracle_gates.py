@@ -197,3 +197,44 @@ def test_eval_fns_base_vs_extension(orc, kind, params):
         cext += [c, 0]
     ext = orc.gate_eval(kind, params, wext, consts=cext, pi_hash=pih, ext=True)
     assert np.array_equal(ext[0::2], base) and not ext[1::2].any()
+
+
+@pytest.mark.parametrize("kind,params,degree,nconst", [
+    (G_CONSTANT, [2], 1, 2), (G_PUBLIC_INPUT, [], 1, 0), (G_ARITHMETIC, [20], 3, 2), (G_BASE_SUM, [2, 32], 2, 0), (G_BASE_SUM, [4, 16], 4, 0),
+    (G_RANDOM_ACCESS, [4, 4, 2], 5, 2), (6, [], 7, 0),
+    (G_U32_ARITHMETIC, [6], 4, 0), (G_U32_ADD_MANY, [3, 9], 4, 0), (G_U32_SUBTRACTION, [11], 4, 0), (G_U32_RANGE_CHECK, [8], 4, 0),
+    (G_COMPARISON, [32, 16], 4, 0),
+])
+def test_low_degree(orc, kind, params, degree, nconst):
+    """gate_testing.rs:20-63 `test_low_degree`, the property test every gate file of the reference runs
+    (arithmetic_u32.rs:520-525, add_many_u32.rs:404-409, subtraction_u32.rs:385-390, range_check_u32.rs:250-255,
+    comparison.rs:594-601): wires and constants that are random polynomials of degree < 32, evaluated on a domain
+    2^ceil(log2(degree + 1)) times larger; every constraint's values interpolate to a polynomial of degree <= 31 * degree --
+    the DECLARED degree of the gate, which is what the selector grouping and the quotient degree factor rely on."""
+    rng = _rng(1000 + 31 * kind + len(params))
+    wsize = 32
+    rate_bits = int(np.ceil(np.log2(degree + 1)))
+    m = wsize << rate_bits
+
+    def low_degree_column():
+        c = np.zeros(m, dtype=np.uint64)
+        c[:wsize] = rng.integers(0, P, size=wsize, dtype=np.uint64)
+        return orc.ntt(c)          # values of a degree < 32 polynomial on the size-m subgroup
+
+    wires = np.stack([low_degree_column() for _ in range(234)])
+    consts = np.stack([low_degree_column() for _ in range(nconst)]) if nconst else np.zeros((0, m), dtype=np.uint64)
+    pih = tuple(int(x) for x in rng.integers(0, P, size=4, dtype=np.uint64))
+    rows = [orc.gate_eval(kind, params, np.ascontiguousarray(wires[:, i]), consts=[int(x) for x in consts[:, i]], pi_hash=pih) for i in range(m)]
+    vals = np.stack(rows, axis=1)   # [num_constraints][m]
+    assert vals.shape[0] > 0
+    worst = 0
+    for t in range(vals.shape[0]):
+        coeffs = orc.ntt(np.ascontiguousarray(vals[t]), inverse=True)
+        nz = np.nonzero(coeffs)[0]
+        deg = int(nz.max()) if nz.size else 0
+        worst = max(worst, deg)
+        assert deg <= (wsize - 1) * degree, (t, deg)
+    # the bound is tight for at least one constraint of every gate with non-linear constraints (a declared degree that is
+    # too generous would waste selector groups; plonky2's test only checks the upper bound, this is an extra sanity check)
+    if degree > 1:
+        assert worst > (wsize - 1) * (degree - 1), worst

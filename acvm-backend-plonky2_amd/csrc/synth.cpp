@@ -263,6 +263,34 @@ void fill_row(Builder &b, const GateDef &g, uint32_t row, gl_t *lc /* local cons
 
 extern "C" {
 
+// The 135 wires of ONE PoseidonGate row (plonky2 gates/poseidon.rs layout: inputs 0..11, outputs 12..23, swap 24, deltas 25..28,
+// S-box inputs of full rounds 1..3 at 29..64, of the 22 partial rounds at 65..86, of full rounds 26..29 at 87..134) for the given
+// twelve inputs with swap = 0: what the gate's generator derives.  Used by translate.py's build() for the in-circuit hash
+// of the public inputs (circuit_builder.rs build(): hash_n_to_hash_no_pad + PublicInputGate).
+void p2synth_poseidon_gate_row(const uint64_t *in12, uint64_t *wires135) {
+  gl_t prc[360];
+  poseidon_round_constants_host(prc);
+  gl_t st[12];
+  for (int i = 0; i < 135; i++) wires135[i] = 0;
+  for (int i = 0; i < 12; i++) wires135[i] = st[i] = in12[i];
+  for (int rd = 0; rd < 30; rd++) {
+    for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], prc[12 * rd + i]);
+    if (rd < 4 || rd >= 26) {
+      if (rd != 0) {
+        const int base = rd < 4 ? 29 + 12 * (rd - 1) : 87 + 12 * (rd - 26);
+        for (int i = 0; i < 12; i++) wires135[base + i] = st[i];
+      }
+      for (int i = 0; i < 12; i++) st[i] = poseidon_sbox(st[i]);
+    } else {
+      wires135[65 + (rd - 4)] = st[0];
+      st[0] = poseidon_sbox(st[0]);
+    }
+    poseidon_mds(st);
+  }
+  for (int i = 0; i < 12; i++) wires135[12 + i] = st[i];
+}
+
+
 // mix: "arith" | "sha" | "ecdsa" | "grammar".  Returns 0 ok.  Outputs are malloc'ed; free
 // with p2synth_free.  wires_out is [num_wires][2^d] column-major.
 // num_pi > 0 adds what `build()` adds for public inputs: PoseidonGate rows hashing them (overwrite-mode

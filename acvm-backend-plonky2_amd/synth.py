@@ -58,3 +58,15 @@ def make_circuit(degree_bits, mix="arith", seed=1, num_public_inputs=0, num_wire
     if num_public_inputs:
         return b, w, pis[:num_public_inputs].copy()
     return b, w
+
+
+def poseidon_gate_row(inputs):
+    """The 135 wires of one PoseidonGate row for twelve inputs, swap = 0 (csrc/synth.cpp p2synth_poseidon_gate_row)."""
+    lib = _lib()
+    x = np.ascontiguousarray(np.array([int(v) for v in inputs], dtype=np.uint64))
+    assert x.size == 12
+    out = np.zeros(135, dtype=np.uint64)
+    lib.p2synth_poseidon_gate_row.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.p2synth_poseidon_gate_row.restype = None
+    lib.p2synth_poseidon_gate_row(x.ctypes.data, out.ctypes.data)
+    return out

@@ -27,16 +27,22 @@ Rust; this file exists so that the named SHA256 circuit can be built and proved 
 import numpy as np
 
 from .prover import build_blob
+from .synth import poseidon_gate_row
 
 P = 0xFFFFFFFF00000001
 NUM_WIRES, NUM_ROUTED, NUM_OPS, BASE_SUM_LIMBS = 234, 80, 20, 63
-G_NOOP, G_CONSTANT, G_PUBLIC_INPUT, G_ARITHMETIC, G_BASE_SUM = 0, 1, 2, 3, 4
+G_NOOP, G_CONSTANT, G_PUBLIC_INPUT, G_ARITHMETIC, G_BASE_SUM, G_POSEIDON = 0, 1, 2, 3, 4, 6
 
 
 class CircuitBuilder:
     """The slice of plonky2's CircuitBuilder<GoldilocksField, 2> (wide_ecc_config, mod.rs:69) the translators use."""
 
-    def __init__(self, seed=2024):
+    def __init__(self, seed=2024, num_wires=NUM_WIRES):
+        # num_wires: 234 = wide_ecc_config (what the reference builds with today, mod.rs:69); 135 = standard_recursion_config
+        # (what the two proofs the reference ships were built with: tests/test_translate.py reproduces their circuits).
+        # Both have 80 routed wires, so ArithmeticGate holds 20 operations and BaseSumGate<2> 63 limbs in either.
+        self.num_wires = num_wires
+        self.public_inputs = []   # targets, in registration order (circuit_builder.rs register_public_input)
         self.parent = []
         self.const_of, self.consts = {}, {}
         self.rows = []            # gate instances in creation order
@@ -93,6 +99,9 @@ class CircuitBuilder:
 
     def assert_zero(self, x):
         self.connect(x, self.zero())
+
+    def register_public_input(self, t):
+        self.public_inputs.append(t)
 
     # -- gadgets/arithmetic.rs --------------------------------------------------------------------
     def arithmetic(self, c0, c1, m0, m1, addend):
@@ -216,9 +225,24 @@ class CircuitBuilder:
     def build(self, witness_values):
         """witness_values: {target: value}.  Returns (blob, wires) for CircuitData(blob).prove(wires)."""
         zero = self.zero()
+        # circuit_builder.rs build(): the public inputs are hashed IN CIRCUIT -- hash_n_to_hash_no_pad::<PoseidonHash>, an
+        # overwrite-mode sponge: one PoseidonGate row per 8 inputs, swap wire tied to zero, the state starts as twelve copies of
+        # `zero` -- and the first four outputs are routed to a PublicInputGate added right behind; no public inputs: the hash is
+        # four copies of `zero` and no PoseidonGate exists (the reference's basic_div / basic_if circuits show both cases)
+        state = [zero] * 12
+        for off in range(0, len(self.public_inputs), 8):
+            chunk = self.public_inputs[off:off + 8]
+            state = list(chunk) + state[len(chunk):]
+            row = {"kind": "poseidon", "in": state, "out": [self.add_virtual_target() for _ in range(12)], "swap": zero}
+            self.rows.append(row)
+            self.events.append(("poseidon", row))
+            state = row["out"]
+        pi_hash = state[:4]
         rows = list(self.rows)
         pi_row = len(rows)
-        const_list = list(self.consts.items())
+        # ConstantGate rows: plonky2 walks constants_to_targets sorted by the constant's canonical value, two per gate (both
+        # reference circuits: 0, 1 | 2^63, p - 1 and 0, 1 | p - 1, -)
+        const_list = sorted(self.consts.items())
         const_rows = (len(const_list) + 1) // 2
         used = pi_row + 1 + const_rows
         d = max(2, (used - 1).bit_length())
@@ -227,11 +251,13 @@ class CircuitBuilder:
         kinds = {("noop",)} if used < n else set()
         kinds |= {("const",), ("pi",)}
         for r in rows:
-            kinds.add(("arith",) if r["kind"] == "arith" else ("basesum", r["L"]))
+            kinds.add(("arith",) if r["kind"] == "arith" else ("poseidon",) if r["kind"] == "poseidon" else ("basesum", r["L"]))
         spec = {("noop",): (0, "NoopGate", (G_NOOP, (0, 0, 0, 0), 0, 0)),
                 ("const",): (1, "ConstantGate { num_consts: 2 }", (G_CONSTANT, (2, 0, 0, 0), 1, 2)),
                 ("pi",): (1, "PublicInputGate", (G_PUBLIC_INPUT, (0, 0, 0, 0), 1, 0)),
-                ("arith",): (3, "ArithmeticGate { num_ops: 20 }", (G_ARITHMETIC, (NUM_OPS, 0, 0, 0), 3, 2))}
+                ("arith",): (3, "ArithmeticGate { num_ops: 20 }", (G_ARITHMETIC, (NUM_OPS, 0, 0, 0), 3, 2)),
+                ("poseidon",): (7, "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>",
+                                (G_POSEIDON, (0, 0, 0, 0), 7, 0))}
         for k in kinds:
             if k[0] == "basesum":
                 spec[k] = (2, "BaseSumGate { num_limbs: %d } + Base: 2" % k[1], (G_BASE_SUM, (2, k[1], 0, 0), 2, 0))
@@ -252,14 +278,22 @@ class CircuitBuilder:
                 for k, op in enumerate(g["ops"]):
                     for j, t in enumerate(op):
                         put(t, r, 4 * k + j)
+            elif g["kind"] == "poseidon":
+                row_gate[r] = index[("poseidon",)]
+                g["row"] = r
+                for j, t in enumerate(g["in"]):
+                    put(t, r, j)
+                for j, t in enumerate(g["out"]):
+                    put(t, r, 12 + j)
+                put(g["swap"], r, 24)
             else:
                 row_gate[r] = index[("basesum", g["L"])]
                 put(g["sum"], r, 0)
                 for j, t in enumerate(g["limbs"]):
                     put(t, r, 1 + j)
         row_gate[pi_row] = index[("pi",)]
-        for i in range(4):                          # hash of zero public inputs = four copies of `zero`
-            put(zero, pi_row, i)
+        for i in range(4):                          # (no public inputs: four copies of `zero`)
+            put(pi_hash[i], pi_row, i)
         for i, (c, t) in enumerate(const_list):
             r = pi_row + 1 + i // 2
             row_gate[r] = index[("const",)]
@@ -273,7 +307,8 @@ class CircuitBuilder:
         for cl in cells.values():
             for (r0, c0), (r1, c1) in zip(cl, cl[1:]):
                 copies.append((r0, c0, r1, c1))
-        blob = build_blob(d, gates, row_gate, row_consts, np.array(copies, dtype=np.uint32).reshape(-1, 4))
+        blob = build_blob(d, gates, row_gate, row_consts, np.array(copies, dtype=np.uint32).reshape(-1, 4),
+                          num_public_inputs=len(self.public_inputs), num_wires=self.num_wires)
         # witness: the generators, in creation order, until nothing changes
         val = {}
         for c, t in const_list:
@@ -297,6 +332,14 @@ class CircuitBuilder:
                         rest.append(ev)
                         continue
                     self._set(val, out, (c0 * a % P * b + c1 * c) % P)
+                elif ev[0] == "poseidon":
+                    ins = [val.get(self.find(t)) for t in ev[1]["in"]]
+                    if any(v is None for v in ins):
+                        rest.append(ev)
+                        continue
+                    ev[1]["wires"] = poseidon_gate_row(ins)
+                    for j, t in enumerate(ev[1]["out"]):
+                        self._set(val, t, int(ev[1]["wires"][12 + j]))
                 elif ev[0] == "split":
                     v = val.get(self.find(ev[1]))
                     if v is None:
@@ -317,7 +360,11 @@ class CircuitBuilder:
             if len(rest) == len(pending):
                 raise ValueError("witness generation is stuck: some inputs were not assigned")
             pending = rest
-        wires = np.zeros((NUM_WIRES, n), dtype=np.uint64)
+        W = self.num_wires
+        wires = np.zeros((W, n), dtype=np.uint64)
+        for g in rows:                              # the PoseidonGate's internal wires (deltas, S-box inputs): its generator's
+            if g["kind"] == "poseidon":
+                wires[:135, g["row"]] = g["wires"]
         for rt, cl in cells.items():
             v = val.get(rt)
             if v is None:
@@ -328,7 +375,9 @@ class CircuitBuilder:
         # circuit_builder.rs randomize_unused_pi_wires: every wire of the PublicInputGate row after the hash, routed
         # or not, gets a random value (so no wire column of a real witness is zero in every row)
         wires[4:NUM_ROUTED, pi_row] = self.rng.integers(0, P, size=NUM_ROUTED - 4, dtype=np.uint64)
-        wires[NUM_ROUTED:, pi_row] = self.rng.integers(0, P, size=NUM_WIRES - NUM_ROUTED, dtype=np.uint64)
+        wires[NUM_ROUTED:, pi_row] = self.rng.integers(0, P, size=W - NUM_ROUTED, dtype=np.uint64)
+        self.public_input_values = [val[self.find(t)] for t in self.public_inputs]
+        self.pi_row = pi_row
         self.values = val
         return blob, wires
 
@@ -419,8 +468,8 @@ SHA256_K = [
 class CircuitBuilderFromAcirToPlonky2:
     """mod.rs:37-330, for programs given as Python data (see the module docstring)."""
 
-    def __init__(self):
-        self.builder = CircuitBuilder()
+    def __init__(self, num_wires=NUM_WIRES):
+        self.builder = CircuitBuilder(num_wires=num_wires)
         self.witness_target_map = {}
 
     def _target(self, w):
@@ -497,9 +546,15 @@ class CircuitBuilderFromAcirToPlonky2:
                 else [b.and_(p, q) for p, q in zip(x.bits, y.bits)])
         self.witness_target_map[output] = self.convert_binary_number_to_number(BinaryDigitsTarget(bits))
 
-    def translate_circuit(self, opcodes, public_parameters=()):
-        if public_parameters:
-            raise NotImplementedError("public parameters (PoseidonGate rows of build()) are not restated here")
+    def translate_circuit(self, opcodes, public_parameters=(), private_parameters=()):
+        # mod.rs:290-310 _register_witnesses_from_acir_circuit: public parameters first -- a fresh target each, registered as a
+        # Plonky2 public input -- then the private ones (return values are NOT public inputs)
+        for w in public_parameters:
+            t = self.builder.add_virtual_target()
+            self.builder.register_public_input(t)
+            self.witness_target_map[w] = t
+        for w in private_parameters:
+            self._target(w)
         for op in opcodes:
             if op[0] == "assert_zero":
                 self.translate_assert_zero(*op[1:])
@@ -517,6 +572,10 @@ class CircuitBuilderFromAcirToPlonky2:
         inputs; outputs given are checked against what the circuit forces).  Returns (blob, wires)."""
         vals = {self.witness_target_map[w]: v for w, v in acir_witness.items() if w in self.witness_target_map}
         return self.builder.build(vals)
+
+    def public_inputs(self):
+        """Values of the registered public inputs, in order (after build): what p2gpu_prove takes beside the wires."""
+        return list(self.builder.public_input_values)
 
     def witness_value(self, w):
         return self.builder.value_of(self.witness_target_map[w])

@@ -153,7 +153,7 @@ class MiniBuilder:
         pi_row = n_arith
         for i in range(4):              # hash of zero public inputs = four copies of `zero`
             cell.setdefault(zero, []).append((pi_row, i))
-        const_list = list(self.consts.items())
+        const_list = sorted(self.consts.items())   # plonky2 build(): constants_to_targets sorted by canonical value (pinned by the reference circuits)
         const_rows = (len(const_list) + 1) // 2
         for i, (c, t) in enumerate(const_list):
             cell.setdefault(t, []).append((pi_row + 1 + i // 2, i % 2))

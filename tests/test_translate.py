@@ -156,3 +156,99 @@ def test_identical_arithmetic_operations_share_their_output(pkg):
     b = cb.mul_add(y, x, z)                              # operand order is part of the key, as upstream
     assert b != a and sum(len(r["ops"]) for r in cb.rows if r["kind"] == "arith") == ops_before + 1
     assert cb.mul(x, y) != a and cb.mul(x, y) == cb.mul(x, y)
+
+
+# ---- the translator against circuits the REFERENCE built -------------------------------------------------------------------------
+# The two proofs the reference ships (example_programs/basic_{if,div}/proofs/*.proof) leak their whole circuit and witness
+# (tests/golden/reference_proofs.py).  Decoding the ArithmeticGate rows of those circuits with the reference's own translator in
+# hand (assert_zero_translator.rs:25-38: constant first, then the linear terms, then the quadratic ones, every step a
+# builder.add(term, acc)) gives back the ACIR the programs had been compiled to -- src/main.nr of each program says the same
+# thing in Noir -- and the restated translator must then rebuild the reference's circuit BIT FOR BIT: gate table, selector
+# columns, gate constants (ConstantGate rows in the order of the constants' canonical values), sigma polynomials, and every wire
+# value except the ones build() randomises in the PublicInputGate row.  The proofs predate wide_ecc_config: 135 wires.
+def _reference_programs():
+    a, b, cond, ncond, t1, t2, r, ret = range(8)
+    basic_if = dict(            # fn main(a, b, cond: bool) -> pub Field { if cond { a } else { b } }    a = 4, b = 2, cond = 1
+        opcodes=[("range", cond, 1),
+                 ("assert_zero", [], [(P - 1, cond), (P - 1, ncond)], 1),          # ncond = 1 - cond
+                 ("assert_zero", [(1, a, cond)], [(P - 1, t1)], 0),                 # t1 = a * cond
+                 ("assert_zero", [(1, b, ncond)], [(P - 1, t2)], 0),                # t2 = b * ncond
+                 ("assert_zero", [], [(P - 1, r), (1, t1), (1, t2)], 0),           # r = t1 + t2
+                 ("assert_zero", [], [(1, r), (P - 1, ret)], 0)],                  # return value
+        public=(), private=(a, b, cond), witness={a: 4, b: 2, cond: 1, ncond: 0, t1: 4, t2: 0, r: 4, ret: 4})
+    x, y, inv, q, ret = range(5)
+    half = pow(2, P - 2, P)
+    basic_div = dict(           # fn main(x, y: pub Field) -> pub Field { y / x }    x = 2, y = 1
+        opcodes=[("assert_zero", [(1, x, inv)], [], P - 1),                        # x * inv = 1 (inv comes from a Brillig call)
+                 ("assert_zero", [(1, y, inv)], [(P - 1, q)], 0),                   # q = y * inv
+                 ("assert_zero", [], [(1, q), (P - 1, ret)], 0)],
+        public=(y,), private=(x,), witness={x: 2, y: 1, inv: half, q: half, ret: half})
+    return {"basic_if": basic_if, "basic_div": basic_div}
+
+
+@pytest.mark.parametrize("name", ["basic_if", "basic_div"])
+def test_translator_rebuilds_the_reference_circuits(pkg, orc, name):
+    sys.path.insert(0, GOLDEN)
+    import reference_proofs as rp
+
+    ref, prog = rp.ReferenceCase(name), _reference_programs()[name]
+    cb = pkg.translate.CircuitBuilderFromAcirToPlonky2(num_wires=135)
+    cb.translate_circuit(prog["opcodes"], public_parameters=prog["public"], private_parameters=prog["private"])
+    blob, wires = cb.build(prog["witness"])
+    assert blob.tobytes() == ref.blob().tobytes()          # header, gate table, k_is, selectors + gate constants, sigmas
+    assert cb.public_inputs() == list(ref.public_inputs)
+    pi_row = cb.builder.pi_row
+    mine, theirs = wires.reshape(135, -1).copy(), ref.wires.copy()
+    assert (theirs[4:, pi_row] != 0).all()                 # build() randomised every unused wire of the PublicInputGate row
+    mine[4:, pi_row] = theirs[4:, pi_row]                  # ... which is the one thing a rebuild cannot reproduce
+    assert np.array_equal(mine, theirs)
+    # and from there the reference's proof itself: same circuit, same witness, the reference's PoW witness
+    oc = orc.OracleCircuit(blob)
+    proof, _ = oc.prove(mine, public_inputs=ref.public_inputs, pow_hint=ref.pow_witness)
+    assert proof == ref.uncompressed()
+    oc.close()
+
+
+def test_public_parameters_are_hashed_in_circuit(pkg, orc):
+    """Public parameters (mod.rs:290-310) in the shape the reference's own opcode tests use them (test_assert_zero.rs:72-103:
+    3 x + 4 y = 7 with both witnesses public, 9 more to cross the 8-input rate of the in-circuit sponge): one PoseidonGate row
+    per 8 inputs, the proof echoes the public inputs, the verifier accepts, another value is refused."""
+    tr = pkg.translate
+    cb = tr.CircuitBuilderFromAcirToPlonky2()
+    pub = list(range(11))
+    ops = [("assert_zero", [], [(3, 0), (4, 1)], P - 7)] + [("assert_zero", [], [(P - 1, i), (1, i + 1)], P - 1) for i in range(2, 10)]
+    cb.translate_circuit(ops, public_parameters=pub)
+    wit = {0: 1, 1: 1}
+    wit.update({i: 100 + i for i in range(2, 11)})
+    blob, wires = cb.build(wit)
+    assert sum(1 for r in cb.builder.rows if r["kind"] == "poseidon") == 2 and int(blob[:256].view(np.uint32)[24]) == 11
+    pis = cb.public_inputs()
+    assert pis == [1, 1] + list(range(102, 111))
+    oc = orc.OracleCircuit(blob)
+    proof, _ = oc.prove(wires, public_inputs=pis)
+    assert oc.verify(proof) and proof[-8 * 11:] == b"".join(int(v).to_bytes(8, "little") for v in pis)
+    bad = list(pis)
+    bad[3] += 1
+    assert not oc.verify(proof[:-8 * 11] + b"".join(int(v).to_bytes(8, "little") for v in bad))
+    oc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["basic_if", "basic_div"])
+def test_gpu_proves_the_translated_reference_programs(pkg, name):
+    """Opcodes -> restated translator -> p2gpu_build_blob -> MI355X: the reference's own proof bytes (its PoW witness as hint)."""
+    sys.path.insert(0, GOLDEN)
+    import reference_proofs as rp
+
+    ref, prog = rp.ReferenceCase(name), _reference_programs()[name]
+    cb = pkg.translate.CircuitBuilderFromAcirToPlonky2(num_wires=135)
+    cb.translate_circuit(prog["opcodes"], public_parameters=prog["public"], private_parameters=prog["private"])
+    blob, wires = cb.build(prog["witness"])
+    w = wires.reshape(135, -1).copy()
+    w[4:, cb.builder.pi_row] = ref.wires[4:, cb.builder.pi_row]
+    cd = pkg.CircuitData(blob)
+    cd.set("pow_hint", ref.pow_witness)
+    proof = cd.prove(np.ascontiguousarray(w), public_inputs=cb.public_inputs())
+    assert proof.to_bytes() == ref.uncompressed()
+    assert cd.compress(proof.to_bytes()) == ref.compressed      # ... and the file the reference's CLI wrote, byte for byte
+    cd.close()

@@ -27,9 +27,10 @@ struct ProfScope {
 };
 
 // ---- ntt.hip ----
+constexpr int NTT_MAX_ROUNDS = 6;  // rounds of <= 3 layers in one pass: 12 layers are 4, a 2^13 tile's 13 layers are 5
 struct NttPass {
   uint32_t s, a, tb, nrounds;
-  uint32_t r[4], tw_off[4];
+  uint32_t r[NTT_MAX_ROUNDS], tw_off[NTT_MAX_ROUNDS];
 };
 struct NttPlan {
   uint32_t d = 0;

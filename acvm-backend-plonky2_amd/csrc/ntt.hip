@@ -147,7 +147,7 @@ __device__ __forceinline__ void dft_regs(gl_t (&v)[1 << LOGR]) {
 // swz(a ^ b) = swz(a) ^ swz(b): a lane's eight addresses are swz(base) ^ swz(j << beta0), the second term wave-uniform.
 __device__ __forceinline__ uint32_t pidx(uint32_t e) { return e ^ ((e >> 4) & 7u) ^ ((e >> 3) & 0x18u); }
 
-constexpr int MAX_ROUNDS = 4;
+constexpr int MAX_ROUNDS = NTT_MAX_ROUNDS;
 #ifndef NTT_PHI
 #define NTT_PHI 0  // 1: butterfly networks on signed a + b*2^32 components (glphi.hpp).  Measured on MI355X (d = 17):
                    // 21 % fewer VALU per radix-16 round, but 150-200 VGPRs instead of 98 (2-3 waves per SIMD
@@ -694,6 +694,10 @@ NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse) {
     np.s = ps.s; np.a = ps.a; np.tb = ps.tb;
     split_rounds(ps.a, rr);
     np.nrounds = (uint32_t)rr.size();
+    if (np.nrounds > (uint32_t)MAX_ROUNDS) {  // (cannot happen for tiles of <= 2^16 elements)
+      delete p;
+      return nullptr;
+    }
     uint32_t beta = ps.tb;
     for (uint32_t i = 0; i < np.nrounds; i++) {
       np.r[i] = rr[i];

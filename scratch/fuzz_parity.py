@@ -4,7 +4,7 @@ structure of the unused wire columns (zeroed, extra rows, values in the Poseidon
 routed when the witness allows it, sparse with a random split)."""
 import sys
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").getcwd())
 import __graft_entry__ as entry
 import torch
 pkg = entry.load_package(); orc = entry.load_oracle()

@@ -71,3 +71,19 @@ def test_blob_header_layout(pkg):
     assert h[26] == 9 and wires.shape == (234, 64) and wires.dtype == np.uint64
     ng, nc = int(h[23]), int(h[5])
     assert blob.nbytes == 256 + 48 * ng + 8 * (80 + (nc + 80) * 64)
+
+
+def test_numbers_table_is_generated_from_the_committed_bench_lines():
+    """profiles/NUMBERS.md is the one place current numbers live (DESIGN.md quotes none that it does not need): it must be what
+    profiles/numbers.py makes of the newest committed bench lines, not a hand-edited copy."""
+    import subprocess
+    import sys
+
+    path = os.path.join(ROOT, "profiles", "NUMBERS.md")
+    before = open(path).read()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "numbers.py")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    after = open(path).read()
+    if after != before:
+        open(path, "w").write(before)
+    assert after == before

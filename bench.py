@@ -888,7 +888,7 @@ def main():
                     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
                                                                             "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
                     try:
-                        r = subprocess.run(cmd, capture_output=True, text=True, timeout=180 * scale_, env=env)
+                        r = subprocess.run(cmd, capture_output=True, text=True, timeout=120 * scale_, env=env)
                         gp = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-400:]}
                     except Exception as e:
                         gp = {"error": str(e)[:300]}
@@ -900,7 +900,7 @@ def main():
 
         import threading
         scale_ = 1 << max(0, d - 17)
-        deadline = 420.0 * scale_
+        deadline = 300.0 * scale_
         th_ = threading.Thread(target=sharded_leg, daemon=True)
         th_.start()
         th_.join(deadline)

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void pow_kernel(PowState st0, uint32_t pos, ui
 #pragma unroll
     for (int j = 0; j < 12; j++) st[j] = gl_canon(st[j]);
   } else {
-    keccak_permutation12(st);
+    keccak_permutation12<8>(st);  // the response is word 7: the third layer of the onion (words 8..11) is never looked at
   }
   const uint64_t resp = st[7];
   if (pow_bits == 0 || (resp >> (64 - pow_bits)) == 0) atomicMin(result, (unsigned long long)w);

@@ -305,14 +305,18 @@ P2_HD void dig_to_elems(const dig_t &d, gl_t out[4]) {
 }
 
 // KeccakPermutation::permute ("hash onion" with rejection sampling)
+// NEED: how many words of the new state the caller will look at (12 = the whole permutation).  The onion produces them four
+// at a time, one Keccak-f per layer: the proof-of-work check reads word 7 only, i.e. two layers instead of three (words
+// 8..11 of `st` are then left as they were -- NOT a permutation of the state any more, only its first NEED words)
+template <int NEED = 12>
 P2_HD void keccak_permutation12(gl_t st[12]) {
   uint64_t h[4];
   keccak256_words(st, 12, h);
   int got = 0;
   for (;;) {
-    for (int i = 0; i < 4 && got < 12; i++)
+    for (int i = 0; i < 4 && got < NEED; i++)
       if (h[i] < GL_P) st[got++] = h[i];
-    if (got == 12) break;
+    if (got >= NEED) break;
     uint64_t h2[4];
     keccak256_words(h, 4, h2);
     for (int i = 0; i < 4; i++) h[i] = h2[i];

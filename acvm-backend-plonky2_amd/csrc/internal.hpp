@@ -39,9 +39,6 @@ struct NttPlan {
   std::vector<NttPass> passes;
   gl_t *ptw = nullptr;   // device: packed per-round twiddle tables
   size_t table_len = 0;
-  uint32_t *fsync = nullptr;  // device: work-queue state of the fused two-pass kernel (two-pass plans only)
-  int fused = 0;              // 0: one launch per pass; 1 / 2: ntt_fused_kernel (ntt.hip)
-  uint32_t fused_lag = 2;
 };
 // which global cosets a sharded launch covers: local index z <-> global coset first + z * stride
 struct CosetMap {
@@ -49,11 +46,6 @@ struct CosetMap {
 };
 NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse);
 void ntt_plan_destroy(NttPlan *p);
-// mode / lag < 0: leave as is
-void ntt_plan_set_fused(NttPlan *p, int mode, int lag);
-// true once a bounded wait inside the fused two-pass kernel has expired in this process (its output is then
-// garbage): checked at every stream synchronisation of the prover, reported as P2GPU_E_DEVICE
-bool ntt_fused_failed();
 // src [cols][n] (or [cosets][cols][n] when src_per_coset), dst [cosets][cols][n]; stride_cols != 0: the
 // launch covers `cols` columns of a batch that has stride_cols columns per coset (chunked pipelines).
 // scale (DIT only): [cosets][n] multiplied into the input; post: multiplied into the output.
@@ -121,7 +113,6 @@ void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d,
                      uint32_t nblk, bool first, bool last, uint64_t *state, dig_t *dig, const VirtCols *virt = nullptr);
 void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m, const gl_t *prc = nullptr);
 // every level below one with m <= 4096 nodes per coset, down to cap_per nodes per coset, in one launch
-bool merkle_tail_fuses(const gl_t *prc);
 size_t merkle_tail_from(const gl_t *prc);
 // host_mirror (optional, page-locked, [cosets][cap_per]): returns true when the final level was also written there
 bool merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc = nullptr,

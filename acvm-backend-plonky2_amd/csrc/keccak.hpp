@@ -99,17 +99,7 @@ __device__ __forceinline__ uint64_t krot(uint64_t x) {
     a00 ^= (RC);                                                                                                       \
   }
 
-#ifndef P2_KECCAK_SCHED
-#define P2_KECCAK_SCHED 1  // device code: the explicitly ordered round pair of keccak_sched.inc (gen_keccak_sched.py)
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && P2_KECCAK_SCHED
-#include "keccak_sched.inc"
-#endif
-
-#ifndef P2_KECCAK_FIXED
-#define P2_KECCAK_FIXED 1  // leaf-hash kernels: the explicit-register permutation of keccak_fixed.inc (gen_keccak_fixed.py)
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && P2_KECCAK_FIXED
+#if defined(__HIP_DEVICE_COMPILE__)
 // Keccak-f with the sponge state in FIXED physical registers v[P2_KF_BASE ...) for the whole life of a kernel: the 24 rounds
 // unrolled, registers assigned so that no v_bitop3_b32 has its three sources in one VGPR bank, no compiler-inserted wait
 // states (gen_keccak_fixed.py; 11.3 vs 10.3 Gperm/s for the compiler-allocated ordered stream, 9.7 for hipcc's own code).
@@ -145,33 +135,6 @@ P2_HD void keccak_f1600(uint64_t st[25]) {
       0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
       0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
       0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-#if defined(__HIP_DEVICE_COMPILE__) && P2_KECCAK_SCHED
-  // gfx950: a v_bitop3_b32 retires in 2.2 cycles, a v_alignbit_b32 in 4.15, and the order they come in matters
-  // (profiles/r03_ubench.txt): the round pair is one asm statement per instruction in a scheduled order
-#define P2_KS_LD(i) uint32_t a##i##l = (uint32_t)st[i], a##i##h = (uint32_t)(st[i] >> 32);
-  P2_KS_LD(0) P2_KS_LD(1) P2_KS_LD(2) P2_KS_LD(3) P2_KS_LD(4) P2_KS_LD(5) P2_KS_LD(6) P2_KS_LD(7) P2_KS_LD(8) P2_KS_LD(9)
-  P2_KS_LD(10) P2_KS_LD(11) P2_KS_LD(12) P2_KS_LD(13) P2_KS_LD(14) P2_KS_LD(15) P2_KS_LD(16) P2_KS_LD(17) P2_KS_LD(18)
-  P2_KS_LD(19) P2_KS_LD(20) P2_KS_LD(21) P2_KS_LD(22) P2_KS_LD(23) P2_KS_LD(24)
-#undef P2_KS_LD
-#define P2_KS_C(x, i0, i1, i2, i3, i4)                                                                   \
-  uint32_t c##x##l = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(a##i0##l, a##i1##l, a##i2##l, 0x96), a##i3##l, a##i4##l, 0x96), \
-           c##x##h = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(a##i0##h, a##i1##h, a##i2##h, 0x96), a##i3##h, a##i4##h, 0x96);
-  P2_KS_C(0, 0, 5, 10, 15, 20) P2_KS_C(1, 1, 6, 11, 16, 21) P2_KS_C(2, 2, 7, 12, 17, 22) P2_KS_C(3, 3, 8, 13, 18, 23)
-  P2_KS_C(4, 4, 9, 14, 19, 24)
-#undef P2_KS_C
-#pragma unroll 1
-  for (int r = 0; r < 24; r += 2) {
-    const uint32_t rc0l = (uint32_t)RC[r], rc0h = (uint32_t)(RC[r] >> 32), rc1l = (uint32_t)RC[r + 1], rc1h = (uint32_t)(RC[r + 1] >> 32);
-    P2_KECCAK_ROUND_PAIR_SCHED
-  }
-#define P2_KS_ST(i) st[i] = ((uint64_t)a##i##h << 32) | a##i##l;
-  P2_KS_ST(0) P2_KS_ST(1) P2_KS_ST(2) P2_KS_ST(3) P2_KS_ST(4) P2_KS_ST(5) P2_KS_ST(6) P2_KS_ST(7) P2_KS_ST(8) P2_KS_ST(9)
-  P2_KS_ST(10) P2_KS_ST(11) P2_KS_ST(12) P2_KS_ST(13) P2_KS_ST(14) P2_KS_ST(15) P2_KS_ST(16) P2_KS_ST(17) P2_KS_ST(18)
-  P2_KS_ST(19) P2_KS_ST(20) P2_KS_ST(21) P2_KS_ST(22) P2_KS_ST(23) P2_KS_ST(24)
-#undef P2_KS_ST
-  (void)c0l; (void)c0h; (void)c1l; (void)c1h; (void)c2l; (void)c2h; (void)c3l; (void)c3h; (void)c4l; (void)c4h;
-  return;
-#endif
   uint64_t a00 = st[0], a01 = st[1], a02 = st[2], a03 = st[3], a04 = st[4], a05 = st[5], a06 = st[6], a07 = st[7],
            a08 = st[8], a09 = st[9], a10 = st[10], a11 = st[11], a12 = st[12], a13 = st[13], a14 = st[14],
            a15 = st[15], a16 = st[16], a17 = st[17], a18 = st[18], a19 = st[19], a20 = st[20], a21 = st[21],

@@ -58,7 +58,7 @@ for name in names:
                     sym = [int(mm.group(1)) for ll in lines if (mm := re.match(r"\.set " + re.escape(name) + r"\.num_vgpr, (\d+)", ll))]
                     nfree = sym[0] if sym else None
                 break
-    ok = mx < base and (not scratch or scratch[0] == 0) and endpgm >= 1 and (nfree is None or nfree >= top)
+    ok = mx < base and (not scratch or scratch[0] == 0) and endpgm >= 1 and nfree is not None and nfree >= top
     print(f"{name[:60]:60s} compiler registers up to v{mx} (state v{base}..v{top - 1}), scratch {scratch[0] if scratch else '?'} B, "
           f"next_free_vgpr {nfree}, s_endpgm x{endpgm}: {'ok' if ok else 'VIOLATION'}")
     bad += not ok

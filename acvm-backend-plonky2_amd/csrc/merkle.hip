@@ -175,7 +175,6 @@ __global__ __launch_bounds__(256, V ? P2_LEAFV_WAVES : P2_LEAF_WAVES) void hash_
   }
 }
 
-#if P2_KECCAK_FIXED
 // ---- Keccak leaf hashing with the sponge state in fixed registers (keccak.hpp P2_KF_*) ----------------------------------
 template <int I, int N, class F>
 __device__ __forceinline__ void kf_for(F &&f) {
@@ -366,25 +365,6 @@ __global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void merkle_levels_kf_kernel
     cnt = half;
   }
 }
-// merkle_tail_kernel<0> on the fixed registers.  The level loop holds ONE permutation call site; a lane has at most one node
-// per level (the launcher switches to the tail at <= 2 * blockDim nodes per coset).
-__global__ __launch_bounds__(1024) P2_KF_KERNEL_ATTR void merkle_tail_kf_kernel(dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per) {
-  const uint32_t c = blockIdx.x;
-  while (m > cap_per) {
-    const uint32_t half = m >> 1;
-    const dig_t *in = lvl + (size_t)c * m;
-    dig_t *out = lvl + (size_t)cosets * m + (size_t)c * half;
-    const uint32_t k = threadIdx.x;
-    if (k < half) {
-      const dig_t l = in[k], r = in[k + half];
-      out[k] = kf_two_to_one<0>(l, r);
-    }
-    __syncthreads();
-    lvl += (size_t)cosets * m;
-    m = half;
-  }
-}
-
 // Up to four levels of the top of a Keccak tree per launch, every node hashed by 25 lanes (keccak_f1600_coop): a block of
 // four waves (one per SIMD: eight permutations at a time) owns the complete sub-tree under ONE node of the last level it
 // computes -- with the (k, k + half) pairing of merkle_level_kernel that is the nodes k0 + j * mf of every level above
@@ -479,7 +459,6 @@ __global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void hash_lde_absorb_kf_kern
     });
   }
 }
-#endif
 
 // Leaf hashing for a witness that arrives in column chunks (p2gpu_prove): a Keccak sponge absorbs
 // 17 columns per permutation, in column order, so the rate blocks of the columns already on the
@@ -586,27 +565,6 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(const dig_t *__restri
   out[(size_t)c * half + k] = node_hash<H>(l, r, prc);
 }
 
-// All remaining levels of a tree in ONE launch once a level has <= 4096 nodes per coset: one
-// 1024-thread block per coset walks the levels (each level is one Keccak-f of dependent
-// latency; separate launches would add a boundary per level).  Levels are laid out back to
-// back: level with m nodes per coset at `lvl`, the next one at lvl + cosets * m.
-template <int H>
-__global__ __launch_bounds__(1024) void merkle_tail_kernel(dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per,
-                                                           const gl_t *__restrict__ prc) {
-  const uint32_t c = blockIdx.x;
-  while (m > cap_per) {
-    const uint32_t half = m >> 1;
-    const dig_t *in = lvl + (size_t)c * m;
-    dig_t *out = lvl + (size_t)cosets * m + (size_t)c * half;
-    for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
-      const dig_t l = in[k], r = in[k + half];
-      out[k] = node_hash<H>(l, r, prc);
-    }
-    __syncthreads();
-    lvl += (size_t)cosets * m;
-    m = half;
-  }
-}
 // merkle_coop_kernel for PoseidonHash: twelve lanes per permutation (poseidon_permute_coop), four per wave, sixteen per block of
 // four waves; up to five levels per launch (the first one on all sixteen slots).  two_to_one = the first four words of
 // permute(left[4] || right[4] || 0^4) (hashing.rs compress).
@@ -638,27 +596,14 @@ __global__ __launch_bounds__(256) void merkle_coop_poseidon_kernel(dig_t *lvl, u
     cnt = half;
   }
 }
-// P2GPU_COOP_TAIL=0: the one-lane-per-node tail of rounds 1-2 (A/B measurements)
-static bool coop_tail_on() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("P2GPU_COOP_TAIL");
-    v = (e && *e == '0') ? 0 : 1;
-  }
-  return v == 1;
-}
-// true: merkle_tail takes a Keccak tree from the first level with at most one wave per SIMD on the chip (fused launches);
-// false: from tail_nodes() nodes per coset, as the one-block-per-coset kernels need
-bool merkle_tail_fuses(const gl_t *prc) { return P2_KECCAK_FIXED && !prc && coop_tail_on(); }
-// levels with at most this many nodes (all cosets together) go to merkle_tail (0: the per-coset rule of tail_nodes())
+// levels with at most this many nodes (all cosets together) go to merkle_tail
 size_t merkle_tail_from(const gl_t *prc) {
-  if (!coop_tail_on()) return 0;
-  if (prc) return 16384;                       // Poseidon: twelve lanes per node pay up to four waves per SIMD (~27 vs ~75 us per level)
-  return P2_KECCAK_FIXED ? (size_t)1024 * 64 : 0;  // Keccak: from one wave per SIMD
+  if (prc) return 16384;      // Poseidon: twelve lanes per node pay up to four waves per SIMD (~27 vs ~75 us per level)
+  return (size_t)1024 * 64;   // Keccak: from one wave per SIMD
 }
 bool merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32_t cap_per, const gl_t *prc, dig_t *host_mirror) {
   if (m <= cap_per) return false;
-  if (prc && coop_tail_on()) {
+  if (prc) {
     while (m > cap_per) {
       if ((size_t)cosets * (m >> 1) > 16384) {
         merkle_level(st, lvl, lvl + (size_t)cosets * m, cosets, m, prc);
@@ -679,8 +624,7 @@ bool merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32
     }
     return false;
   }
-#if P2_KECCAK_FIXED
-  if (!prc && coop_tail_on()) {
+  {
     // Keccak: a level with more than 2 048 nodes (two per wave: one wave per SIMD on the chip) is still cheaper one lane
     // per node (7.5 us); below that the 25-lane form (3.5-5 us per level), four levels per launch
     bool mirrored = false;
@@ -716,36 +660,20 @@ bool merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32
     }
     return mirrored;
   }
-#endif
-  uint32_t threads = m / 2 >= 1024 ? 1024 : (m / 2 >= 64 ? m / 2 : 64);
-  ProfScope ps(prc ? "merkle_tail_kernel<1>" : ((P2_KECCAK_FIXED && m / 2 <= threads) ? "merkle_tail_kf_kernel" : "merkle_tail_kernel<0>"),
-               96.0 * cosets * (double)(m - cap_per));
-  if (prc) hipLaunchKernelGGL(merkle_tail_kernel<1>, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per, prc);
-#if P2_KECCAK_FIXED
-  else if (m / 2 <= threads) hipLaunchKernelGGL(merkle_tail_kf_kernel, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per);
-#endif
-  else hipLaunchKernelGGL(merkle_tail_kernel<0>, dim3(cosets), dim3(threads), 0, st, lvl, cosets, m, cap_per, prc);
-  return false;
 }
 
 void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig, const gl_t *prc,
                      const VirtCols *virt) {
   size_t n = (size_t)1 << d;
   uint32_t threads = n >= 256 ? 256 : 64;
-#if P2_KECCAK_FIXED
   // Keccak, a hashed leaf (more than 3 elements) and full 256-lane blocks: the fixed-register sponge (profile names = the
   // symbols rocprofv3 shows)
   const bool kf = !prc && cols * 8 > 25 && n >= 256;
-#else
-  const bool kf = false;
-#endif
   if (virt && virt->cls && virt->first < cols) {  // the wires of a proof with unmaterialised columns (same digests)
     ProfScope ps(prc ? "hash_lde_leaves_kernel<1, true>" : (kf ? "hash_lde_leaves_kf_kernel<true>" : "hash_lde_leaves_kernel<0, true>"),
                  (8.0 * cols + 32.0) * cosets * (double)n);
     if (prc) hipLaunchKernelGGL((hash_lde_leaves_kernel<1, true>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, *virt);
-#if P2_KECCAK_FIXED
     else if (kf) hipLaunchKernelGGL((hash_lde_leaves_kf_kernel<true>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, *virt);
-#endif
     else hipLaunchKernelGGL((hash_lde_leaves_kernel<0, true>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, *virt);
     return;
   }
@@ -753,9 +681,7 @@ void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d,
   ProfScope ps(prc ? "hash_lde_leaves_kernel<1, false>" : (kf ? "hash_lde_leaves_kf_kernel<false>" : "hash_lde_leaves_kernel<0, false>"),
                (8.0 * cols + 32.0) * cosets * (double)n);
   if (prc) hipLaunchKernelGGL((hash_lde_leaves_kernel<1, false>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, VirtCols());
-#if P2_KECCAK_FIXED
   else if (kf) hipLaunchKernelGGL((hash_lde_leaves_kf_kernel<false>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, VirtCols());
-#endif
   else hipLaunchKernelGGL((hash_lde_leaves_kernel<0, false>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, VirtCols());
 }
 void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, uint32_t blk0,
@@ -764,7 +690,6 @@ void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d,
   uint32_t threads = n >= 256 ? 256 : 64;
   ProfScope ps("hash_lde_absorb_kernel", (8.0 * 17 * nblk + (first ? 0 : 200) + (last ? 32 + 8.0 * (cols - 17 * (blk0 + nblk)) : 200)) *
                                              cosets * (double)n);
-#if P2_KECCAK_FIXED
   if (n >= 256) {
     if (virt && virt->cls && virt->first < cols)
       hipLaunchKernelGGL(hash_lde_absorb_kf_kernel<true>, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols,
@@ -774,7 +699,6 @@ void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d,
                          d, blk0, nblk, first ? 1 : 0, last ? 1 : 0, state, dig, VirtCols());
     return;
   }
-#endif
   if (virt && virt->cls && virt->first < cols)
     hipLaunchKernelGGL(hash_lde_absorb_kernel<true>, dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols,
                        d, blk0, nblk, first ? 1 : 0, last ? 1 : 0, state, dig, *virt);
@@ -789,7 +713,7 @@ void hash_fri_leaves(hipStream_t st, const gl_t *vals, uint32_t lg_npc, uint32_t
   uint32_t per = (1u << lg_npc) >> ab;
   uint32_t threads = per >= 256 ? 256 : 64;
   ProfScope ps(prc ? "hash_fri_leaves_kernel<1>" : "hash_fri_leaves_kernel<0>", (16.0 * (1u << ab) + 32.0) * cosets * (double)per);
-  if (prc && coop_tail_on() && (2u << ab) >= 8 && (size_t)cosets * per <= 4096)  // latency-bound: 4 permutations of ~12 us instead of ~75
+  if (prc && (2u << ab) >= 8 && (size_t)cosets * per <= 4096)  // latency-bound: 4 permutations of ~12 us instead of ~75
     hipLaunchKernelGGL(hash_fri_leaves_coop_poseidon_kernel, dim3((cosets * per + 15) / 16), dim3(256), 0, st, vals, lg_npc, ab, cosets, dig, prc);
   else if (prc) hipLaunchKernelGGL(hash_fri_leaves_kernel<1>, dim3((per + threads - 1) / threads, cosets), dim3(threads), 0, st, vals, lg_npc, ab, dig, prc);
   else hipLaunchKernelGGL(hash_fri_leaves_kernel<0>, dim3((per + threads - 1) / threads, cosets), dim3(threads), 0, st, vals, lg_npc, ab, dig, prc);
@@ -797,18 +721,16 @@ void hash_fri_leaves(hipStream_t st, const gl_t *vals, uint32_t lg_npc, uint32_t
 void merkle_level(hipStream_t st, const dig_t *in, dig_t *out, uint32_t cosets, uint32_t m, const gl_t *prc) {
   uint32_t half = m >> 1;
   uint32_t threads = half >= 256 ? 256 : 64;
-  const bool kf_big = P2_KECCAK_FIXED && !prc && (size_t)half * cosets >= (size_t)2 * 1024 * 64;
-  const bool kf_small = P2_KECCAK_FIXED && !prc && !kf_big && threads == 256;
+  const bool kf_big = !prc && (size_t)half * cosets >= (size_t)2 * 1024 * 64;
+  const bool kf_small = !prc && !kf_big && threads == 256;
   ProfScope ps(prc ? "merkle_level_kernel<1>" : (kf_big ? "merkle_level_kf_kernel<1>" : (kf_small ? "merkle_level_kf_kernel<0>" : "merkle_level_kernel<0>")),
                96.0 * cosets * (double)half);
   if (prc) hipLaunchKernelGGL(merkle_level_kernel<1>, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out, m, prc);
-#if P2_KECCAK_FIXED
   // >= 2 waves per SIMD on the whole chip (2 * 1024 SIMDs * 64 lanes): throughput placement; below: a SIMD sees a lone wave
   else if ((size_t)half * cosets >= (size_t)2 * 1024 * 64)
     hipLaunchKernelGGL(merkle_level_kf_kernel<1>, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out, m);
   else if (threads == 256)
     hipLaunchKernelGGL(merkle_level_kf_kernel<0>, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out, m);
-#endif
   else hipLaunchKernelGGL(merkle_level_kernel<0>, dim3((half + threads - 1) / threads, cosets), dim3(threads), 0, st, in, out, m, prc);
 }
 

@@ -28,7 +28,6 @@
 // and back: a 1 MB column-coset does not fit a CU's LDS) -- 2.5 TB/s while the
 // kernel runs, not its limiter.  No MFMA.
 #include "internal.hpp"
-#include "glphi.hpp"
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -148,14 +147,6 @@ __device__ __forceinline__ void dft_regs(gl_t (&v)[1 << LOGR]) {
 __device__ __forceinline__ uint32_t pidx(uint32_t e) { return e ^ ((e >> 4) & 7u) ^ ((e >> 3) & 0x18u); }
 
 constexpr int MAX_ROUNDS = NTT_MAX_ROUNDS;
-#ifndef NTT_PHI
-#define NTT_PHI 0  // 1: butterfly networks on signed a + b*2^32 components (glphi.hpp).  Measured on MI355X (d = 17):
-                   // 21 % fewer VALU per radix-16 round, but 150-200 VGPRs instead of 98 (2-3 waves per SIMD
-                   // instead of 4): LDE 3.42 ms vs 3.22 ms.  Re-measured with the radix-8 rounds (NTT_PER 8): 68-80 VGPRs,
-                   // 6-7 waves per SIMD, no scratch, bit-exact -- and still slower (LDE 1.36 vs 1.21 ms, sha mix; 2.91 vs 2.52
-                   // with 231 dense columns): its 64-bit shifts and adds retire slower than the carry chains they replace.
-                   // It stays an opt-in variant
-#endif
 #ifndef NTT_TILE_BITS
 #define NTT_TILE_BITS 12
 #endif
@@ -194,83 +185,6 @@ __device__ __forceinline__ uint32_t gidx(uint32_t e, uint32_t hi_base, uint32_t 
 // one round: layers on tile bits [beta0, beta0 + LOGR); the group twiddle of position j is
 // theta^(bitrev(j)), theta = w_{2^(s0+LOGR)}^(lo), read from the packed table T[(e-1)*M + lo].
 // MUL = (s0 > 0): the round has general twiddles (the first round of a transform has none).
-#if NTT_PHI
-// The butterfly network runs on a + b*2^32 with signed 64-bit components (glphi.hpp): plain 64-bit
-// adds, shifts for the power-of-two twiddles, compile-time placed renormalisations.  The general
-// twiddle products enter that form straight from their 128-bit value; what goes back to LDS is a
-// u64 congruent to the result (not necessarily < p) -- the next round's product and the pass's
-// final store (gl_canon) take any u64.
-template <int DIT, bool INV, int LOGR, bool MUL>
-__device__ __forceinline__ void round_regs(gl_t *lds, const PassArgs &A, uint32_t TB, uint32_t beta0, uint32_t lo0,
-                                           const gl_t *tw) {
-  constexpr int R = 1 << LOGR;
-  const uint32_t ngroups = 1u << (TB - LOGR);
-  const uint32_t s0 = beta0 - A.tb + A.s;  // log2 M
-  const uint32_t M = 1u << s0;
-  typedef PhiNet<LOGR, DIT, INV, MUL && DIT ? phi_bound_mul().ma : phi_bound_from().ma,
-                 MUL && DIT ? phi_bound_mul().mb : phi_bound_from().mb> Net;
-  for (uint32_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
-    const uint32_t low = g & ((1u << beta0) - 1), high = g >> beta0;
-    const uint32_t base = (high << (beta0 + LOGR)) | low;
-    // global index of `base` modulo M
-    const uint32_t lo = (((base & ((1u << beta0) - 1)) >> A.tb) << A.s) + lo0 + (base & ((1u << A.tb) - 1));
-    phi_t w[R];
-    if constexpr (DIT && LOGR == 4) {
-      // 16 registers of two 64-bit components are 64 VGPRs; with all 16 words and 15 twiddles loaded up
-      // front on top of that the kernel loses half its occupancy.  Layers 0-2 of a DIT network never
-      // cross the two halves of the register array: finish the lower half, then load and finish the
-      // upper half, then the top layer pair by pair straight into LDS.
-      static_for<0, 2>([&](auto hc) {
-        constexpr int h = decltype(hc)::value;
-        gl_t x[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = lds[pidx(base | ((uint32_t)(j + 8 * h) << beta0))];
-        static_for<0, 8>([&](auto jc) {
-          constexpr int j = decltype(jc)::value + 8 * h;
-          if constexpr (MUL && j > 0) w[j] = phi_mul_u64(x[j - 8 * h], tw[(size_t)(brev_c(j, LOGR) - 1) * M + lo]);
-          else w[j] = phi_from(x[j - 8 * h]);
-        });
-        Net::template run_part<0, 3, h>(w);
-        asm volatile("" ::: "memory");  // the other half's loads stay on their side of this point
-      });
-      static_for<0, 8>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        Net::template dit_top<j>(w);
-        lds[pidx(base | ((uint32_t)j << beta0))] = phi_to_u64(w[j]);
-        lds[pidx(base | ((uint32_t)(j + 8) << beta0))] = phi_to_u64(w[j + 8]);
-      });
-    } else {
-      gl_t v[R];
-#pragma unroll
-      for (int j = 0; j < R; j++) v[j] = lds[pidx(base | ((uint32_t)j << beta0))];
-      if constexpr (DIT) {
-        static_for<0, R>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          if constexpr (MUL && j > 0) w[j] = phi_mul_u64(v[j], tw[(size_t)(brev_c(j, LOGR) - 1) * M + lo]);
-          else w[j] = phi_from(v[j]);
-        });
-        Net::run(w);
-#pragma unroll
-        for (int j = 0; j < R; j++) v[j] = phi_to_u64(w[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < R; j++) w[j] = phi_from(v[j]);
-        Net::run(w);
-#pragma unroll
-        for (int j = 0; j < R; j++) v[j] = phi_to_u64(w[j]);
-        if constexpr (MUL) {
-          static_for<1, R>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            v[j] = gl_mul(v[j], tw[(size_t)(brev_c(j, LOGR) - 1) * M + lo]);
-          });
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < R; j++) lds[pidx(base | ((uint32_t)j << beta0))] = v[j];
-    }
-  }
-}
-#else
 template <int DIT, bool INV, int LOGR, bool MUL>
 __device__ __forceinline__ void round_regs(gl_t *lds, const PassArgs &A, uint32_t TB, uint32_t beta0, uint32_t lo0,
                                            const gl_t *tw) {
@@ -327,7 +241,6 @@ __device__ __forceinline__ void round_regs(gl_t *lds, const PassArgs &A, uint32_
     for (int j = 0; j < R; j++) lds[li[j]] = v[j];
   }
 }
-#endif
 
 template <int DIT, bool INV>
 __device__ __forceinline__ void do_round(gl_t *lds, const PassArgs &A, uint32_t TB, uint32_t beta0, uint32_t logr,
@@ -353,22 +266,19 @@ __device__ __forceinline__ void do_round(gl_t *lds, const PassArgs &A, uint32_t 
 // TBC = 12: the full 2^12-element tile with NTT_THREADS lanes -- the global loads/stores of a lane are NTT_PER
 // independent accesses issued back to back (compile-time trip count) so their latencies overlap;
 // TBC = 0: any smaller tile (small transforms), runtime loops.
-// FUSED && l2load: the tile's source was written earlier IN THIS LAUNCH by other workgroups on the same XCD (the
-// fused two-pass kernel below): read it with agent-scope (sc1) loads, which are served by the XCD's L2 and never by
-// this CU's vector L1.
 // waves per SIMD the full-tile kernel is compiled for: 8 = four 512-lane workgroups per CU, i.e. <= 64 VGPRs.  hipcc reaches
 // 59-60 on its own; saying so makes it schedule for that bound (LDE 1.22-1.24 -> 1.205-1.21 ms at 2^20 rows, round 4) and
 // keeps an edit that would silently cost a quarter of the occupancy (every variant above 64 VGPRs measured 20-30 % slower)
 // from compiling into one
 #ifndef NTT_MIN_WAVES
-#if NTT_PHI || NTT_PER != 8
+#if NTT_PER != 8
 #define NTT_MIN_WAVES 1
 #else
 #define NTT_MIN_WAVES 8
 #endif
 #endif
-template <int DIT, bool INV, int TBC, bool FUSED>
-__device__ __forceinline__ void tile_body(gl_t *lds, const PassArgs &A, uint32_t tile, uint32_t col, uint32_t coset, bool l2load) {
+template <int DIT, bool INV, int TBC>
+__device__ __forceinline__ void tile_body(gl_t *lds, const PassArgs &A, uint32_t tile, uint32_t col, uint32_t coset) {
   const uint32_t TB = TBC ? TBC : A.a + A.tb;
   const size_t n = (size_t)1 << A.d;
   const uint32_t runs = 1u << (A.s - A.tb);  // lo-runs per hi block
@@ -395,12 +305,8 @@ __device__ __forceinline__ void tile_body(gl_t *lds, const PassArgs &A, uint32_t
 #ifdef NTT_EXP_NOLOAD   // timing experiment only (wrong results): what the load phase costs
       x[i] = (gl_t)g[i] * 0x9E3779B97F4A7C15ULL;
 #else
-      if (!FUSED || !l2load) x[i] = src[g[i]];
+      x[i] = src[g[i]];
 #endif
-    }
-    if (FUSED && l2load) {  // workgroup-uniform
-#pragma unroll
-      for (int i = 0; i < PER; i++) x[i] = __hip_atomic_load(src + g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (scale) {
       gl_t sc[PER];
@@ -424,7 +330,15 @@ __device__ __forceinline__ void tile_body(gl_t *lds, const PassArgs &A, uint32_t
   // whose bits [9, 12) are w (lane g = 64 w + l holds base = (g >> beta << (beta + 3)) | (g & (2^beta - 1)) and its 8
   // strides): consecutive such rounds exchange data inside a wave only, and a wave's LDS operations execute in order --
   // no workgroup barrier between them.
-  auto wave_private = [&](uint32_t beta, uint32_t r) { return TBC == 12 && NTT_PER == 8 && r == 3 && beta + 3 <= 9; };
+  // That argument needs: 512 lanes in wave64 (wave w = lanes [64 w, 64 w + 64)), ONE group per lane (g == threadIdx.x: the
+  // trip count of round_regs' loop is 1) and round_regs' base = (g >> beta << (beta + 3)) | low split -- tied down here so that
+  // an edit to any of them fails to compile instead of racing on LDS.
+  static_assert(TBC != 12 || NTT_PER != 8 || NTT_THREADS == 512, "wave-private rounds: one radix-8 group per lane of a 2^12 tile");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "wave-private rounds assume wave64: gfx950 (CDNA has no wave32 mode) is the only target of this file"
+#endif
+  const bool one_group_per_lane = (1u << (TB - 3)) == blockDim.x;
+  auto wave_private = [&](uint32_t beta, uint32_t r) { return TBC == 12 && NTT_PER == 8 && one_group_per_lane && r == 3 && beta + 3 <= 9; };
   if (DIT) {
     uint32_t beta = A.tb;
     for (uint32_t i = 0; i < A.nrounds; i++) {
@@ -451,11 +365,6 @@ __device__ __forceinline__ void tile_body(gl_t *lds, const PassArgs &A, uint32_t
     if (post) {
 #pragma unroll
       for (int i = 0; i < PER; i++) x[i] = gl_mul(x[i], A.post);
-    } else {
-#if NTT_PHI
-#pragma unroll
-      for (int i = 0; i < PER; i++) x[i] = gl_canon(x[i]);  // LDS holds congruent, not canonical, words
-#endif
     }
 #ifdef NTT_EXP_NOSTORE  // timing experiment only (wrong results): what the store phase costs
     if ((x[0] ^ x[1] ^ x[2] ^ x[3] ^ x[4] ^ x[5] ^ x[6] ^ x[7]) == 0x1234567ULL)
@@ -465,11 +374,7 @@ __device__ __forceinline__ void tile_body(gl_t *lds, const PassArgs &A, uint32_t
   } else {
     for (uint32_t e = threadIdx.x; e < tsize; e += blockDim.x) {
       gl_t x = lds[pidx(e)];
-#if NTT_PHI
-      x = post ? gl_mul(x, A.post) : gl_canon(x);
-#else
       if (post) x = gl_mul(x, A.post);
-#endif
       dst[gidx(e, hi_base, lo0, A.s, A.tb)] = x;
     }
   }
@@ -491,140 +396,7 @@ __global__ __launch_bounds__(TBC ? NTT_THREADS : 256, TBC ? NTT_MIN_WAVES : 1) v
   // v * (unit column of the fixed row) to v * (that unit column's transform): structured_fill_kernel wrote them,
   // nothing to do here (block-uniform scalar branch).
   if (A.colnz != nullptr && A.colnz[col] != 2u) return;
-  tile_body<DIT, INV, TBC, false>(lds, A, tile, col, coset0, false);
-}
-
-// ---- both passes of a two-pass transform in ONE launch (13 <= d <= 21) ------------------------------------------
-// A 2^d-point transform with d > 12 is two passes with an all-to-all dependency between them: every tile of the second
-// pass reads a slice of every tile the first pass wrote for the same (column, coset).  As two launches the 8n-word
-// intermediate of a column's LDE goes out to HBM and comes back (25n words of traffic per dense column against 9n
-// algorithmic), and every pass drains the chip before the next one starts.  Here the tiles of both passes are ITEMS of
-// per-XCD work queues served by persistent workgroups:
-//   * a workgroup reads the id of the XCD it runs on from the hardware (HW_REG_XCC_ID) and serves THAT queue, so the
-//     two passes of a (column, coset) run on one XCD by construction -- whatever the dispatcher's block -> XCD map is --
-//     and the 2^d-word intermediate is handed over through that XCD's L2 (4 MB; 1 MB per column-coset at d = 17);
-//   * queue position q -> step j = q / 2T, r = q % 2T (T = tiles per pass): r < T is tile r of the FIRST pass of the
-//     step's unit, r >= T is tile r - T of the SECOND pass of the unit `lag` steps back -- second-pass tiles trail
-//     their first-pass tiles by `lag` units, long enough for them to have retired (every first-pass position of a
-//     unit precedes every second-pass position of it, for any lag >= 0);
-//   * units are claimed on demand: step j's unit is coset j % cosets of the queue's column slot j / cosets, and the
-//     workgroup that draws the slot's first item takes the next dense column from a launch-wide counter and publishes
-//     it in the slot table (an XCD that runs fewer workgroups claims fewer columns; one that runs none claims none);
-//   * a first-pass tile ends with: every wave waits for its stores (s_waitcnt vmcnt(0): the data is in L2), barrier,
-//     one lane adds 1 to the unit's counter (agent-scope atomic); a second-pass tile starts with: one lane polls that
-//     counter (relaxed agent-scope loads + s_sleep) until it reads T, barrier, then sc1 loads (L2-served, never this
-//     CU's L1).  No L2 write-back (an agent-scope release would push the intermediate to HBM -- the traffic this kernel
-//     exists to avoid): producer and consumer share the L2 because they share the queue.  P2GPU_NTT_FUSED=2 adds the
-//     agent-scope release / acquire pair of the placement-oblivious protocol (A/B and fall-back).
-// Forward progress: an item waits only for items at EARLIER positions of its own queue (its slot's claim, its unit's
-// first-pass tiles); those were drawn by workgroups that are running and never wait themselves (claims) or wait only
-// for still earlier claims (first-pass tiles).  No assumption about dispatch order or residency.  Every spin is bounded
-// (SPIN_LIMIT polls): on expiry the error word is set, the workgroup goes on, and the launcher's caller reports
-// P2GPU_E_DEVICE at its next synchronisation point instead of hanging the device.
-struct FusedArgs {
-  PassArgs p[2];
-  uint32_t *sync;  // device words, zeroed before every launch: see FS_* below
-  uint32_t *herr;  // page-locked host word (process-wide): set when a bounded spin expires; ntt_fused_failed() reads it
-  uint32_t ncols, cosets, tiles, lag, fenced;
-};
-constexpr uint32_t FS_HEAD = 0;         // queue head of XCD x at sync[FS_HEAD + 16 * x] (one cache line apart)
-constexpr uint32_t FS_NEXT_COL = 128;   // launch-wide column counter
-constexpr uint32_t FS_ERROR = 129;      // != 0: a bounded spin expired
-constexpr uint32_t FS_SLOTS = 256;      // slot table of XCD x at sync[FS_SLOTS + x * FS_SLOT_STRIDE + slot]
-constexpr uint32_t FS_MAX_COLS = 1024;  // columns per fused launch (more: the two-launch path)
-constexpr uint32_t FS_MAX_LAG = 32;
-constexpr uint32_t FS_SLOT_STRIDE = FS_MAX_COLS + FS_MAX_LAG + 8;
-constexpr uint32_t FS_COUNT = FS_SLOTS + 8 * FS_SLOT_STRIDE;  // first-pass tiles done, per (column, coset)
-constexpr uint32_t FS_WORDS = FS_COUNT + FS_MAX_COLS * 8;
-constexpr uint32_t FS_DONE = 1;         // slot value: no column left (a column c is stored as c + 2; 0 = not claimed yet)
-constexpr uint32_t SPIN_LIMIT = 1u << 20;  // x (s_sleep 8 + one L2 load) ~ 0.5-1 s
-
-__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// poll *p until pred(value); bounded
-template <class P>
-__device__ __forceinline__ uint32_t spin_until(const uint32_t *p, uint32_t *err, uint32_t *herr, P pred) {
-  uint32_t v = ld_relaxed(p);
-  for (uint32_t i = 0; !pred(v); i++) {
-    if (i >= SPIN_LIMIT) {
-      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(herr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      break;
-    }
-    __builtin_amdgcn_s_sleep(8);
-    v = ld_relaxed(p);
-  }
-  return v;
-}
-
-template <int DIT, bool INV>
-__global__ __launch_bounds__(NTT_THREADS, 8) void ntt_fused_kernel(FusedArgs F) {
-  extern __shared__ gl_t lds[];
-  uint32_t *ctl = (uint32_t *)(lds + (1u << NTT_TILE_BITS));  // 2 words behind the tile (same LDS object)
-  // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this workgroup's CU belongs to
-  const uint32_t xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
-  uint32_t *head = F.sync + FS_HEAD + 16u * xcd;
-  uint32_t *slots = F.sync + FS_SLOTS + xcd * FS_SLOT_STRIDE;
-  uint32_t *err = F.sync + FS_ERROR;
-  const uint32_t T = F.tiles, per_step = 2u * T;
-  uint32_t signal = UINT32_MAX;  // counter index of the first-pass tile this workgroup has just stored
-  for (;;) {
-    if (signal != UINT32_MAX) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's tile stores have reached L2
-    __syncthreads();  // ... every wave's; and nobody reads the tile in LDS or ctl any more
-    if (threadIdx.x == 0) {
-      if (signal != UINT32_MAX) {
-        if (F.fenced & 1u) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __hip_atomic_fetch_add(F.sync + FS_COUNT + signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      const uint32_t q = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t j = q / per_step, r = q % per_step, phase = r >= T ? 1u : 0u;
-      uint32_t v = 0;  // 0: nothing to do for this item; FS_DONE: the queue is finished; else column + 2
-      if (!(phase && j < F.lag)) {
-        const uint32_t js = phase ? j - F.lag : j;
-        const uint32_t slot = js / F.cosets, coset = js % F.cosets;
-        if (slot >= FS_SLOT_STRIDE) {
-          v = FS_DONE;  // cannot happen (the table covers every column plus the lag); never index past it
-          __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(F.herr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        } else if (phase == 0 && r == 0 && coset == 0) {  // this item opens the slot: claim the next dense column
-          uint32_t c;
-          do {
-            c = __hip_atomic_fetch_add(F.sync + FS_NEXT_COL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } while (c < F.ncols && F.p[0].colnz != nullptr && F.p[0].colnz[c] != 2u);
-          v = c < F.ncols ? c + 2u : FS_DONE;
-          __hip_atomic_store(slots + slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-          v = spin_until(slots + slot, err, F.herr, [](uint32_t x) { return x != 0; });
-          if (v == 0) v = FS_DONE;  // spin expired: give up on this queue
-        }
-        if (v == FS_DONE) {
-          if (phase == 0) v = 0;  // no first-pass work left; second-pass items of earlier units may still follow
-        } else if (phase) {
-          const uint32_t need = (F.fenced & 4u) ? 0u : T;  // bit 2: timing experiment only (wrong results): no wait
-          spin_until(F.sync + FS_COUNT + (v - 2u) * F.cosets + coset, err, F.herr, [need](uint32_t x) { return x >= need; });
-          if (F.fenced & 1u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-      }
-      if (ld_relaxed(err) != 0) v = FS_DONE;  // a spin expired somewhere: every workgroup leaves at its next item
-      ctl[0] = q;
-      ctl[1] = v;
-    }
-    __syncthreads();
-    const uint32_t q = ctl[0], v = ctl[1];
-    if (v == FS_DONE) break;
-    signal = UINT32_MAX;
-    if (v == 0) continue;
-    const uint32_t j = q / per_step, r = q % per_step, phase = r >= T ? 1u : 0u, tile = phase ? r - T : r;
-    const uint32_t coset = (phase ? j - F.lag : j) % F.cosets, col = v - 2u;
-    // ONE instance of the tile code for both passes, its PassArgs read from the kernel-argument segment by pass index
-    // (two inlined instances kept both argument sets live in SGPRs: 32 spilled, 99 VGPRs, half the occupancy)
-    tile_body<DIT, INV, NTT_TILE_BITS, true>(lds, F.p[phase], tile, col, coset, phase != 0 && !(F.fenced & 8u));  // bit 3: experiment, plain loads
-    if (!phase) signal = col * F.cosets + coset;
-  }
+  tile_body<DIT, INV, TBC>(lds, A, tile, col, coset0);
 }
 
 static inline size_t lds_bytes(uint32_t TB) { return std::max<size_t>((size_t)1 << TB, 256) * sizeof(gl_t); }  // no padding: pidx() is a permutation of every 256-element block
@@ -654,15 +426,11 @@ static void split_rounds(uint32_t a, std::vector<uint32_t> &r) {
   }
 }
 
-static int fused_mode_default();
-static uint32_t fused_lag_default();
 NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse) {
   NttPlan *p = new NttPlan();
   p->d = d;
   p->dit = dit;
   p->inverse = inverse;
-  p->fused = fused_mode_default();
-  p->fused_lag = fused_lag_default();
   const uint32_t TBMAX = NTT_TILE_BITS;
   const uint32_t b = d < TBMAX ? d : TBMAX;
   struct P { uint32_t s, a, tb; };
@@ -709,13 +477,6 @@ NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse) {
     p->passes.push_back(np);
   }
   p->table_len = total;
-  // the fused two-pass kernel's queue heads, slot tables and per-unit counters (zeroed in-stream before every launch)
-  if (p->passes.size() == 2 && p->passes[0].a + p->passes[0].tb == TBMAX && p->passes[1].a + p->passes[1].tb == TBMAX) {
-    if (hipMalloc((void **)&p->fsync, FS_WORDS * sizeof(uint32_t)) != hipSuccess) {
-      delete p;
-      return nullptr;
-    }
-  }
   if (total) {
     if (hipMalloc((void **)&p->ptw, total * sizeof(gl_t)) != hipSuccess) {
       delete p;
@@ -741,7 +502,6 @@ NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse) {
 void ntt_plan_destroy(NttPlan *p) {
   if (!p) return;
   if (p->ptw) (void)hipFree(p->ptw);
-  if (p->fsync) (void)hipFree(p->fsync);
   delete p;
 }
 
@@ -842,95 +602,21 @@ static void fill_pass_args(PassArgs &A, const NttPlan *plan, size_t i, const gl_
   A.cols_grid = cols; A.cosets = cosets;
 }
 // same spelling as rocprofv3's demangled kernel names, so the bench line and profiles/ agree
-static const char *pass_kernel_name(const NttPlan *plan, bool fused, bool full) {
+static const char *pass_kernel_name(const NttPlan *plan, bool full) {
   // string literals: the profiler keeps the pointer
-  static const char *const names[3][2][2] = {
+  static const char *const names[2][2][2] = {
       {{"ntt_pass_kernel<0, false, 0>", "ntt_pass_kernel<0, true, 0>"}, {"ntt_pass_kernel<1, false, 0>", "ntt_pass_kernel<1, true, 0>"}},
-      {{"ntt_pass_kernel<0, false, 12>", "ntt_pass_kernel<0, true, 12>"}, {"ntt_pass_kernel<1, false, 12>", "ntt_pass_kernel<1, true, 12>"}},
-      {{"ntt_fused_kernel<0, false>", "ntt_fused_kernel<0, true>"}, {"ntt_fused_kernel<1, false>", "ntt_fused_kernel<1, true>"}}};
+      {{"ntt_pass_kernel<0, false, 12>", "ntt_pass_kernel<0, true, 12>"}, {"ntt_pass_kernel<1, false, 12>", "ntt_pass_kernel<1, true, 12>"}}};
   // (the "12" in the names is NTT_TILE_BITS of the default build)
-  return names[fused ? 2 : (full ? 1 : 0)][plan->dit ? 1 : 0][plan->inverse ? 1 : 0];
+  return names[full ? 1 : 0][plan->dit ? 1 : 0][plan->inverse ? 1 : 0];
 }
-// NttPlan::fused: 0 = one launch per pass (default: the fused kernel measured SLOWER on MI355X, DESIGN.md / profiles/r04_lde_fused.md),
-// 1 = both passes of a two-pass transform in one launch, 2 = the same with agent-scope release / acquire fences around the
-// hand-over.  Default from P2GPU_NTT_FUSED, per handle through the knob "ntt_fused"; P2GPU_NTT_LAG / knob "ntt_lag": units the
-// second pass trails the first by.
-static int fused_mode_default() {
-  static const int m = [] { const char *e = getenv("P2GPU_NTT_FUSED"); return e ? atoi(e) : 0; }();
-  return m;
-}
-static uint32_t fused_lag_default() {
-  static const uint32_t l = [] { const char *e = getenv("P2GPU_NTT_LAG"); return (uint32_t)std::min(std::max(e ? atoi(e) : 2, 0), (int)FS_MAX_LAG); }();
-  return l;
-}
-void ntt_plan_set_fused(NttPlan *p, int mode, int lag) {
-  if (!p) return;
-  if (mode >= 0) p->fused = mode;
-  if (lag >= 0) p->fused_lag = (uint32_t)std::min(lag, (int)FS_MAX_LAG);
-}
-static uint32_t *fused_host_error_word() {
-  static uint32_t *w = [] {
-    uint32_t *p = nullptr;
-    if (hipHostMalloc((void **)&p, 64, hipHostMallocDefault) != hipSuccess) return (uint32_t *)nullptr;
-    *p = 0;
-    return p;
-  }();
-  return w;
-}
-bool ntt_fused_failed() {
-  uint32_t *w = fused_host_error_word();
-  return w != nullptr && __atomic_load_n(w, __ATOMIC_RELAXED) != 0;
-}
-static uint32_t fused_grid(const void *kernel, size_t lds) {
-  // persistent workgroups: as many as the device holds at once (a larger grid would only queue workgroups that find
-  // their queues empty; a smaller one leaves CUs idle).  Per device, cached per kernel.
-  static std::mutex mu;
-  static std::map<std::pair<int, const void *>, uint32_t> cache;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = cache.find({dev, kernel});
-  if (it != cache.end()) return it->second;
-  int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, NTT_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-  static const int cap = [] { const char *e = getenv("P2GPU_NTT_WG_PER_CU"); return e ? atoi(e) : 0; }();
-  if (cap > 0) per_cu = std::min(per_cu, cap);
-  const uint32_t g = (uint32_t)per_cu * (uint32_t)cus;
-  cache[{dev, kernel}] = g;
-  return g;
-}
+// (Both passes of a two-pass transform in ONE launch -- per-XCD work queues, the intermediate handed over through L2 -- was built in
+// round 4, bit-exact, and measured slower and heavier on HBM than two launches: profiles/r04_lde_fused.md; removed in round 5,
+// `git show 33c653e:acvm-backend-plonky2_amd/csrc/ntt.hip` has it.)
 static void ntt_passes(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
                        const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_all, const uint32_t *colnz) {
   const uint32_t d = plan->d;
   const size_t np = plan->passes.size();
-  if (np == 2 && plan->fsync != nullptr && plan->fused != 0 && cols >= 8 && cols <= FS_MAX_COLS && cosets <= 8 &&
-      fused_host_error_word() != nullptr) {
-    FusedArgs F;
-    F.herr = fused_host_error_word();
-    for (size_t i = 0; i < 2; i++) fill_pass_args(F.p[i], plan, i, src, dst, cols, cosets, scale, post, src_per_coset, cm, stride_all, colnz);
-    F.sync = plan->fsync;
-    F.ncols = cols; F.cosets = cosets; F.tiles = F.p[0].tiles;
-    F.lag = plan->fused_lag;
-    F.fenced = (plan->fused == 2 ? 1u : 0u) | (getenv("P2GPU_NTT_EXP_NOWAIT") ? 4u : 0u) | (getenv("P2GPU_NTT_EXP_PLAIN") ? 8u : 0u);
-    const size_t lb = lds_bytes(NTT_TILE_BITS) + 16;
-    const void *kfn = plan->dit ? (plan->inverse ? (const void *)ntt_fused_kernel<1, true> : (const void *)ntt_fused_kernel<1, false>)
-                                : (plan->inverse ? (const void *)ntt_fused_kernel<0, true> : (const void *)ntt_fused_kernel<0, false>);
-    const uint64_t items = (uint64_t)cols * cosets * 2 * F.tiles;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(fused_grid(kfn, lb), items);
-    // algorithmic HBM bytes: the source once (shared by the cosets of a column when it has no coset dimension), the result once
-    const double bytes = 8.0 * (double)cols * ((size_t)1 << d) * (cosets + (src_per_coset ? (double)cosets : 1.0));
-    (void)hipMemsetAsync(plan->fsync, 0, FS_WORDS * sizeof(uint32_t), st);
-    ProfScope psx(pass_kernel_name(plan, true, true), bytes);
-    if (plan->dit) {
-      if (plan->inverse) hipLaunchKernelGGL((ntt_fused_kernel<1, true>), dim3(grid), dim3(NTT_THREADS), lb, st, F);
-      else hipLaunchKernelGGL((ntt_fused_kernel<1, false>), dim3(grid), dim3(NTT_THREADS), lb, st, F);
-    } else {
-      if (plan->inverse) hipLaunchKernelGGL((ntt_fused_kernel<0, true>), dim3(grid), dim3(NTT_THREADS), lb, st, F);
-      else hipLaunchKernelGGL((ntt_fused_kernel<0, false>), dim3(grid), dim3(NTT_THREADS), lb, st, F);
-    }
-    return;
-  }
   for (size_t i = 0; i < np; i++) {
     PassArgs A;
     fill_pass_args(A, plan, i, src, dst, cols, cosets, scale, post, src_per_coset, cm, stride_all, colnz);
@@ -940,7 +626,7 @@ static void ntt_passes(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_
     // expected HBM bytes: every output element is written once; the input is read once per element, except
     // that the cosets of one (tile, column) share their source through one XCD's L2 (first LDE pass)
     const double bytes = 8.0 * (double)cols * ((size_t)1 << d) * (cosets + (A.src_single ? 1.0 : (double)cosets));
-    ProfScope psx(pass_kernel_name(plan, false, TB == NTT_TILE_BITS), bytes);
+    ProfScope psx(pass_kernel_name(plan, TB == NTT_TILE_BITS), bytes);
     const size_t lb = lds_bytes(TB);
 #define P2_LAUNCH(DITV, INVV)                                                                                \
   do {                                                                                                       \

@@ -363,20 +363,6 @@ int tree_alloc(Batch &b, uint32_t C, size_t m0, size_t cap_per) {
   return 0;
 }
 
-// Levels with more nodes per coset than this are one grid-wide launch each; below it, one block per
-// coset walks the remaining levels in a single launch (merkle.hip merkle_tail_kernel).  A tail level
-// costs one dependent Keccak-f (~9 us) however few nodes it has, but only as long as every lane has at
-// most one node: with 1024 lanes per coset that is 2048 nodes per coset (measured on MI355X, d = 17:
-// switching at 4096 nodes: 9.09 ms per proof, 2048: 8.93, 1024: 8.75, 512: 8.86; P2GPU_TAIL_NODES overrides).
-size_t tail_nodes() {
-  static size_t v = 0;
-  if (!v) {
-    const char *e = getenv("P2GPU_TAIL_NODES");
-    v = e && atoi(e) >= 2 ? (size_t)atoi(e) : 1024;
-  }
-  return v;
-}
-
 // device copy of the Poseidon round constants when the circuit's hasher is PoseidonHash, nullptr for Keccak
 const gl_t *hprc(const p2gpu_circuit *c) { return c->hasher == 1 ? c->d_prc_hash.p : nullptr; }
 
@@ -385,20 +371,15 @@ const gl_t *hprc(const p2gpu_circuit *c) { return c->hasher == 1 ? c->d_prc_hash
 // sleep on it instead -- a woken thread costs ~10-30 us more per round trip, but a process with several proofs in
 // flight no longer burns one CPU per host thread while the GPU works (4 spinning threads per GPU are 32 CPUs on an
 // 8-GPU node: more than the 16-CPU cgroup quota of the MI355X boxes, where the spinning would throttle the ranks).
-int ntt_health() {
-  if (!ntt_fused_failed()) return 0;
-  set_err("a bounded wait inside ntt_fused_kernel expired (work-queue hand-over between its two passes): results discarded");
-  return P2GPU_E_DEVICE;
-}
 int wait_stream(p2gpu_circuit *c) {
   if (!c->blocking_sync) {
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return ntt_health();
+    return 0;
   }
   if (!c->sync_event) HIP_TRY(hipEventCreateWithFlags(&c->sync_event, hipEventBlockingSync | hipEventDisableTiming));
   HIP_TRY(hipEventRecord(c->sync_event, c->stream));
   HIP_TRY(hipEventSynchronize(c->sync_event));
-  return ntt_health();
+  return 0;
 }
 
 int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
@@ -415,7 +396,7 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
   for (size_t l = 1; l < b.level_off.size(); l++) {
     // the rest of the tree in merkle_tail: a few launches of several levels each (Keccak), or one (Poseidon)
     const size_t from = merkle_tail_from(hprc(c));
-    if (from ? (size_t)CL * (m >> 1) <= from : m <= tail_nodes()) {
+    if ((size_t)CL * (m >> 1) <= from) {
       mirrored = merkle_tail(c->stream, b.dig.p + b.level_off[l - 1], CL, (uint32_t)m, (uint32_t)cap_target, hprc(c), mirror);
       m = cap_target;
       break;
@@ -1182,6 +1163,9 @@ int ensure_device() {
   int dev = 0;
   (void)hipGetDevice(&dev);
   g_device = dev;
+  // the implicit form of p2gpu_init(&dev, 1): p2gpu_circuit_create_on(dev) and p2gpu_peer_access see a one-device list
+  g_devices.assign(1, dev);
+  g_peer_access.assign(1, -1);
   return 0;
 }
 
@@ -1733,13 +1717,6 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
     // proofs made with the knob off overwrite every column without touching the marks: forget them
     if (c->wire_clean.p) HIP_TRY(hipMemsetAsync(c->wire_clean.p, 0, sizeof(uint32_t) * c->W, c->stream));
   }
-  else if (k == "ntt_fused" || k == "ntt_lag") {
-    // both passes of the 2^d-point transforms in one launch (ntt_fused_kernel): same bytes, measured slower -- off by default
-    const int mode = k == "ntt_fused" ? (int)value : -1, lag = k == "ntt_lag" ? (int)value : -1;
-    ntt_plan_set_fused(c->plan_inv, mode, lag);
-    ntt_plan_set_fused(c->plan_fwd, mode, lag);
-    for (NttPlan *p : c->fri_plans) ntt_plan_set_fused(p, mode, lag);
-  }
   else if (k == "profile") {
     flush_kstats(c);
     c->profile = (int)value;
@@ -2185,7 +2162,7 @@ int p2gpu_ifft_batch(const uint64_t *vals, size_t ncols, unsigned d, uint64_t *c
   ntt_plan_destroy(plan);
   HIP_TRY(e1);
   HIP_TRY(e2);
-  return ntt_health();
+  return P2GPU_OK;
 } P2GPU_CATCH
 
 int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned rate_bits, uint64_t *lde_out) try {
@@ -2211,14 +2188,17 @@ int p2gpu_lde_batch(const uint64_t *coeffs, size_t ncols, unsigned d, unsigned r
   ntt_plan_destroy(plan);
   HIP_TRY(e1);
   HIP_TRY(e2);
-  if (int rc = ntt_health()) return rc;
   for (uint32_t r = 0; r < C; r++)
     for (size_t col = 0; col < ncols; col++)
       for (size_t k = 0; k < n; k++) lde_out[col * C * n + C * k + r] = tmp[((size_t)r * ncols + col) * n + k];
   return P2GPU_OK;
 } P2GPU_CATCH
 
-int p2gpu_field_selftest(const uint64_t *a, const uint64_t *b, size_t n, uint64_t bad_out[16]) try {
+static int field_selftest_words(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *bad_out, size_t words);
+// the entry point of rounds 1-3 keeps its contract: EIGHT words (a caller built against the old header passes uint64_t[8])
+int p2gpu_field_selftest(const uint64_t *a, const uint64_t *b, size_t n, uint64_t bad_out[8]) { return field_selftest_words(a, b, n, bad_out, 8); }
+int p2gpu_field_selftest16(const uint64_t *a, const uint64_t *b, size_t n, uint64_t bad_out[16]) { return field_selftest_words(a, b, n, bad_out, 16); }
+static int field_selftest_words(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *bad_out, size_t words) try {
   if (int rc = ensure_device()) return rc;
   if (!a || !b || !bad_out || n == 0 || n > ((size_t)1 << 28)) return P2GPU_E_ARG;
   Scratch S;
@@ -2230,7 +2210,7 @@ int p2gpu_field_selftest(const uint64_t *a, const uint64_t *b, size_t n, uint64_
   HIP_TRY(hipMemcpyAsync(db, b, 8 * n, hipMemcpyHostToDevice, S.st));
   HIP_TRY(hipMemsetAsync(bad, 0, 128, S.st));
   field_selftest(S.st, da, db, (uint32_t)n, bad);
-  HIP_TRY(hipMemcpyAsync(bad_out, bad, 128, hipMemcpyDeviceToHost, S.st));
+  HIP_TRY(hipMemcpyAsync(bad_out, bad, 8 * words, hipMemcpyDeviceToHost, S.st));
   HIP_TRY(hipStreamSynchronize(S.st));
   return P2GPU_OK;
 } P2GPU_CATCH

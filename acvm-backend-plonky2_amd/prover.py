@@ -110,6 +110,7 @@ def load_library():
     lib.p2gpu_commit_values.argtypes = [vp, sz, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, u8p]
     lib.p2gpu_hash_rows.argtypes = [vp, sz, sz, u8p]
     lib.p2gpu_field_selftest.argtypes = [vp, vp, sz, vp]
+    lib.p2gpu_field_selftest16.argtypes = [vp, vp, sz, vp]
     lib.p2gpu_device_info.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(sz)]
     lib.p2gpu_peer_access.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
     lib.p2gpu_circuit_create_on.argtypes = [u8p, sz, ctypes.c_int, ctypes.POINTER(vp)]
@@ -647,7 +648,7 @@ def field_selftest(a, b):
     y = np.ascontiguousarray(b, dtype=np.uint64)
     assert x.shape == y.shape and x.ndim == 1
     bad = np.zeros(16, dtype=np.uint64)
-    _check(lib.p2gpu_field_selftest(x.ctypes.data, y.ctypes.data, x.size, bad.ctypes.data))
+    _check(lib.p2gpu_field_selftest16(x.ctypes.data, y.ctypes.data, x.size, bad.ctypes.data))
     return bad
 
 

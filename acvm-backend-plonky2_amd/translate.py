@@ -548,12 +548,15 @@ class CircuitBuilderFromAcirToPlonky2:
 
     def translate_circuit(self, opcodes, public_parameters=(), private_parameters=()):
         # mod.rs:290-310 _register_witnesses_from_acir_circuit: public parameters first -- a fresh target each, registered as a
-        # Plonky2 public input -- then the private ones (return values are NOT public inputs)
-        for w in public_parameters:
+        # Plonky2 public input -- then the private ones (return values are NOT public inputs).  The reference holds
+        # both in BTreeSets (acir Circuit::public_parameters / private_parameters): iteration is by ascending witness index
+        # whatever order the caller lists them in, and that order fixes the public-input order (hence the in-circuit
+        # Poseidon hash, the circuit digest and the proof bytes)
+        for w in sorted(set(public_parameters)):
             t = self.builder.add_virtual_target()
             self.builder.register_public_input(t)
             self.witness_target_map[w] = t
-        for w in private_parameters:
+        for w in sorted(set(private_parameters)):
             self._target(w)
         for op in opcodes:
             if op[0] == "assert_zero":

@@ -26,7 +26,7 @@ the same process, separate passes collect what the JSON line reports beside `val
   * `cpu_baseline` (N = 1): the oracle = CPU port, on THIS workload, all host cores, unscaled;
   * `cold_process` (N = 1): a fresh process that reads the circuit and the witness, creates the handle and proves ONCE
     (the plain-C `p2gpu-prove --timing`) -- what one invocation of the reference's CLI would see (prove_action.rs:27-43).
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line (< 6 KB: compact_line) on rank 0; the full result goes to bench_detail.json beside it (--detail).
 
 `--gpus N` with N > 1 is self-contained: started WITHOUT torchrun the command itself launches N ranks (one process per
 device, RCCL) and exits non-zero if the box has fewer than N devices; started BY torchrun (WORLD_SIZE set) it is one of
@@ -190,6 +190,10 @@ def counter_clock(kernel, wave_instr_per_launch, launches_per_sec):
             cur = "ecdsa" if "ecdsa" in line else "sha"
         m = re.match(r"^(.*?)\s+launches\s+\d+ avg\s+([\d.]+) us\s+clock ([\d.]+) GHz\s+cycles/VALU wave-instr/SIMD ([\d.]+)", line)
         if m and cur == section and m.group(1).strip() == kernel:
+            if float(m.group(2)) < 100.0:
+                # GRBM_GUI_ACTIVE / 8 / duration is not a clock for a dispatch this short (round 4 read 2.5-3.3 GHz on a 2.4 GHz
+                # part below ~100 us: the counter window is wider than the kernel) -- no cycle figures for such kernels
+                return {}
             cpi = float(m.group(4))
             return {"cycles_per_valu_wave_instr": cpi, "clock_ghz_counter_pass": float(m.group(3)),
                     "clock_ghz_implied_this_run": cpi * wave_instr_per_launch / 1024.0 * launches_per_sec / 1e9,
@@ -217,6 +221,80 @@ def issue_roofline(kernel, launches_per_sec):
         return out
     except Exception:
         return None
+
+
+def _short(x, nd=4):
+    """Floats to `nd` significant digits, recursively: the stdout line is a summary, the detail file keeps full precision."""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    if isinstance(x, dict):
+        return {k: _short(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_short(v, nd) for v in x]
+    return x
+
+
+LINE_LIMIT = 6000   # bytes of the stdout line (the driver's record keeps the last 8 KB of stdout)
+
+
+def compact_line(out, detail_name="bench_detail.json"):
+    """The ONE stdout line: the contract's fields, the latency / host-boundary numbers, `roofline` for ONE kernel and
+    `cpu_baseline`, a few hundred bytes each.  `out` is the full result (what goes to the detail file)."""
+    r = out.get("roofline") or {}
+    iss = r.get("valu_issue") or {}
+    wp = r.get("whole_proof") or {}
+    cfg = out.get("config") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_min", "ms_per_step_max",
+                                    "repeats", "timed_seconds", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["metric"] = str(line["metric"])[:400]
+    line["config"] = {"workload": str(cfg.get("workload"))[:300], "degree_bits": cfg.get("degree_bits"), "lde_rows": cfg.get("lde_rows"),
+                      "mix": cfg.get("mix"), "public_inputs": cfg.get("public_inputs"), "in_flight_per_gpu": out.get("in_flight_per_gpu"),
+                      "parallelism": str(cfg.get("parallelism"))[:200], "proof_bytes": cfg.get("proof_bytes")}
+    for k in ("latency_ms_single_proof", "latency_ms_single_proof_host_witness", "value_host_witness", "cold_process_ms"):
+        line[k] = out.get(k)
+    if (out.get("n_gpus") or 1) > 1 or out.get("peer_access") is not None:
+        for k in ("latency_ms_sharded", "latency_ms_sharded_group", "rccl_ranks", "peer_access", "ranks_share_devices"):
+            line[k] = out.get(k)
+        sh = out.get("sharded") or {}
+        if sh.get("error"):
+            line["sharded_error"] = str(sh["error"])[:200]
+        gr = sh.get("group") or {}
+        if gr.get("error"):
+            line["sharded_group_error"] = str(gr["error"])[:200]
+        opr = gr.get("one_process_replicas") or {}
+        if opr:
+            line["one_process_replicas_proofs_per_sec"] = opr.get("proofs_per_sec")
+    if r:
+        line["roofline"] = {
+            "kernel": r.get("kernel"), "bound": r.get("bound"), "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit"),
+            "frac": r.get("frac"), "traffic": r.get("traffic"), "traffic_source": r.get("traffic_source"),
+            "avg_launch_ms": r.get("avg_launch_ms"), "launches_per_proof": r.get("launches_per_proof"),
+            "algorithmic_bytes_per_launch": r.get("algorithmic_bytes_per_launch"),
+            "timing": "lone launches: per-launch HIP events on the launch stream, one proof on the GPU at a time",
+            "hbm": {"frac": r.get("frac")},
+            "valu_issue": ({"frac": iss.get("frac"), "frac_of_mix_ceiling": iss.get("frac_of_mix_ceiling"), "peak": iss.get("peak"),
+                            "unit": iss.get("unit"), "source": iss.get("source")} if iss else None),
+            "whole_proof": {"algorithmic_bytes": wp.get("algorithmic_bytes"), "frac_lone": wp.get("frac"), "frac_at_value": wp.get("frac_at_throughput")},
+        }
+    cb = out.get("cpu_baseline")
+    if cb:
+        if "error" in cb:
+            line["cpu_baseline"] = {"error": str(cb["error"])[:200]}
+        else:
+            st = cb.get("single_thread") or {}
+            line["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                    "sample": str(cb.get("sample"))[:330], "seconds": cb.get("seconds"),
+                                    "single_thread": ({"seconds": st.get("seconds"), "cores": 1, "scaled": st.get("scaled")} if "seconds" in st else None)}
+    line["device"] = out.get("device")
+    line["detail"] = detail_name
+    txt = json.dumps(_short(line), separators=(",", ":"))
+    if len(txt) > LINE_LIMIT:   # cannot happen with the caps above; if it ever does, drop prose before numbers
+        for k in ("timing", "traffic_source"):
+            line.get("roofline", {}).pop(k, None)
+        line["metric"] = line["metric"][:120]
+        txt = json.dumps(_short(line), separators=(",", ":"))
+    assert len(txt) <= LINE_LIMIT, len(txt)
+    return txt
 
 
 def effective_cores():
@@ -514,6 +592,8 @@ def main():
     ap.add_argument("--dry", action="store_true",
                     help="rank plumbing only, no GPU work: rendezvous + barrier + max-over-ranks, one JSON line naming the ranks "
                          "(the CPU-side test of `--gpus N`)")
+    ap.add_argument("--detail", default="",
+                    help="where the full result goes (default bench_detail.json beside bench.py); stdout is ONE line under 6 KB")
     ap.add_argument("--timed-only", action="store_true",
                     help="warm-up + timed region only (no host-witness / pipelined / event-profile / CPU passes): the command "
                          "rocprofv3 wraps (scratch/prof.sh), so that its per-kernel averages are those of the timed path")
@@ -927,12 +1007,18 @@ def main():
         W, CS = int(hdr[3]), int(hdr[5]) + int(hdr[4])
         steps_b, total_b = survey_bytes(d, W, CS)
         ms_step = dt / args.steps * 1e3
-        name, st = max(stats.items(), key=lambda kv: kv[1]["ms"])
+        # The roofline is that of ONE kernel, and every figure in it divides by that kernel's LONE launch time (one proof on the GPU
+        # at a time: per-launch HIP events on the library's launch stream, what `rocprofv3 --kernel-trace --stats` of scratch/prof.sh
+        # agrees with).  With S proofs in flight an event pair measures a span the kernel shares with the other proofs' kernels;
+        # span / S is an attribution, not a duration (it printed an HBM fraction of 1.124), so the in-flight
+        # spans are reported in the detail file as spans and nothing is divided by them.  The dominant kernel is the one with
+        # the largest lone time per proof (stable from run to run; the in-flight shares flipped between two kernels).
+        name, st = max(stats_lone.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = st["ms"] / st["launches"]
-        launches_per_proof = st["launches"] / P_inflight
+        launches_per_proof = st["launches"] / P
         step = step_of(name)
-        # SURVEY 8(d) bytes of the kernel's step, shared by every kernel symbol of that step in proportion to its time
-        step_ms = sum(v["ms"] for k, v in stats.items() if step_of(k) == step) or st["ms"]
+        # SURVEY 8(d) bytes of the kernel's step, shared by every kernel symbol of that step in proportion to its (lone) time
+        step_ms = sum(v["ms"] for k, v in stats_lone.items() if step_of(k) == step) or st["ms"]
         alg_per_launch = (steps_b.get(step, 0.0) * (st["ms"] / step_ms)) / launches_per_proof if step else st["bytes"] / st["launches"]
         impl_per_launch = st["bytes"] / st["launches"]
         gbps_alg = alg_per_launch / (avg_ms * 1e-3) / 1e9
@@ -943,15 +1029,16 @@ def main():
         wm_ = wires.reshape(W, -1)
         dense_w = int(((wm_ != 0).sum(axis=1) > 1).sum())
         proc_b = processed_bytes(d, W, CS, dense_w)
-        # every profiled kernel: time, algorithmic bytes (what the launcher counts for the columns it was given) and, from the
-        # newest committed PMC summary, measured HBM traffic and its ratio to the algorithmic bytes
+        # every profiled kernel: LONE time, algorithmic bytes (what the launcher counts for the columns it was given) and, from the
+        # newest committed PMC summary, measured HBM traffic and its ratio to the algorithmic bytes; the in-flight span beside it
         per_kernel = {}
-        for k_, v_ in sorted(stats.items(), key=lambda kv: -kv[1]["ms"]):
+        for k_, v_ in sorted(stats_lone.items(), key=lambda kv: -kv[1]["ms"]):
             tr_, _ = pmc_traffic(k_)
             alg_ = v_["bytes"] / v_["launches"]
             iss_ = issue_roofline(k_, v_["launches"] / (v_["ms"] * 1e-3)) if v_["ms"] > 0 else None
-            per_kernel[k_] = {"ms_per_proof": round(v_["ms"] / P_inflight, 4), "launches_per_proof": v_["launches"] / P_inflight,
-                              "ms_per_proof_lone": round(stats_lone[k_]["ms"] / P, 4) if k_ in stats_lone else None,
+            per_kernel[k_] = {"ms_per_proof_lone": round(v_["ms"] / P, 4), "launches_per_proof": v_["launches"] / P,
+                              "avg_launch_ms_lone": v_["ms"] / v_["launches"],
+                              "span_ms_per_proof_in_flight": round(spans[k_]["ms"] / P_inflight, 4) if k_ in spans else None,
                               "algorithmic_bytes_per_launch": alg_, "traffic_bytes_per_launch": tr_,
                               "traffic_over_algorithmic": (tr_ / alg_) if (tr_ and alg_) else None,
                               "hbm_frac": alg_ / (v_["ms"] / v_["launches"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -959,11 +1046,9 @@ def main():
                               "valu_frac_of_peak": iss_["frac"] if iss_ else None,
                               "valu_frac_of_mix_ceiling": iss_["frac_of_mix_ceiling"] if iss_ else None}
         out = {
-            "metric": (f"prove latency (ms) + proofs/sec at 2^{d + 3} LDE rows, {world} GPU(s).  SURVEY 8(d)'s boundary -- p2gpu_prove, wire matrix in host "
-                       f"RAM -> proof bytes in host RAM: latency_ms_single_proof_host_witness / value_host_witness (N = 1).  `value` (the contract keeps "
-                       f"the PCIe-inclusive rate out of it) = proofs/sec with the witness resident in HBM, {S} proof(s) in flight per GPU, median of "
-                       f"{len(rep_s)} timed region(s); lone resident proof: latency_ms_single_proof"
-                       + ("; ONE proof over the N GPUs: latency_ms_sharded (RCCL, N ranks) / latency_ms_sharded_group (one process)" if world > 1 else "")),
+            "metric": (f"prove latency (ms) + proofs/sec at 2^{d + 3} LDE rows, {world} GPU(s): value = proofs/sec, witness resident in HBM, {S} proof(s) in "
+                       f"flight per GPU; latency_ms_single_proof = lone resident proof; *_host_witness = p2gpu_prove from host RAM (PCIe inside the call)"
+                       + ("; latency_ms_sharded[_group] = ONE proof over the N GPUs (RCCL ranks / one-process device group)" if world > 1 else "")),
             "value": total_proofs / dt,
             "unit": "proofs/sec",
             "n_gpus": world,
@@ -996,57 +1081,45 @@ def main():
                 "proof_bytes": len(proof),
                 "witness": "resident in HBM when the timed region starts (p2gpu_prove_dev); proof bytes returned to host",
             },
-            "roofline": dict({
+            "roofline": {
                 "kernel": name,
-                # the dominant kernel is bound by VALU issue, not by HBM (counters, microbenchmarks): `bound` says so
-                # and `frac` is the issue fraction; the HBM figure of the contract (algorithmic bytes / launch time / 8 TB/s) is
-                # kept beside it under `hbm`.  Without committed counters for this (mix, degree_bits) the issue side is unknown
-                # and the block falls back to the HBM form
-                "bound": "valu-issue" if issue else "hbm",
-                "achieved": issue["achieved"] if issue else gbps_alg,
-                "peak": VALU_PEAK if issue else HBM_PEAK_GBPS,
-                "unit": "lane-instr/s" if issue else "GB/s",
-                "frac": issue["frac"] if issue else gbps_alg / HBM_PEAK_GBPS,
-                "frac_of_mix_ceiling": issue["frac_of_mix_ceiling"] if issue else None,
-                "hbm": {"achieved": gbps_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps_alg / HBM_PEAK_GBPS},
+                # The contract's form: ALGORITHMIC bytes per launch / the kernel's average LONE launch duration / 8 TB/s.  The kernel
+                # is in fact bound by VALU issue (counters + microbenchmarks): `valu_issue` carries that side
+                "bound": "hbm",
+                "achieved": gbps_alg,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": gbps_alg / HBM_PEAK_GBPS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "avg_launch_ms": avg_ms,
                 "launches_per_proof": launches_per_proof,
+                "timing": f"per-launch HIP events on the library's launch stream, one proof on the GPU at a time, {P} proofs after the timed region",
                 "algorithmic_bytes_per_launch": alg_per_launch,
                 "algorithmic_bytes_definition": f"SURVEY.md 8(d) bytes of prover step '{step}' ({steps_b.get(step, 0) / 1e9:.3f} GB per proof) "
                                                 f"/ launches of that step per proof",
                 "implementation_bytes_per_launch": impl_per_launch,
                 "frac_traffic": (traffic / (avg_ms * 1e-3) / 1e9 if traffic else gbps_impl) / HBM_PEAK_GBPS,
+                "valu_issue": issue,
                 "whole_proof": {"algorithmic_bytes": total_b, "achieved": total_b / (single_ms * 1e-3) / 1e9, "unit": "GB/s",
                                 "frac": total_b / (single_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                "note": "B(N) / t_prove of SURVEY.md 8(d) with t_prove = latency_ms_single_proof; the prover is "
-                                        "VALU-issue-bound, see `issue`",
+                                "note": "B(N) / t_prove of SURVEY.md 8(d) with t_prove = latency_ms_single_proof",
                                 "frac_at_throughput": total_b * (total_proofs / world / dt) / 1e9 / HBM_PEAK_GBPS},
-                "issue": issue,
-                "operating_point": f"{S} proof(s) in flight per GPU, as in the timed region: avg_launch_ms = event span / {S} (the launch's share of the chip's "
-                                   f"time); `lone` = the same kernel with one proof on the GPU at a time (what `rocprofv3 --stats` of scratch/prof.sh agrees with)",
-                "avg_launch_span_ms": (spans[name]["ms"] / spans[name]["launches"]) if name in spans else None,
-                "lone": ({"avg_launch_ms": stats_lone[name]["ms"] / stats_lone[name]["launches"],
-                          "hbm_frac": alg_per_launch / (stats_lone[name]["ms"] / stats_lone[name]["launches"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                          "issue_frac": (lambda i_: i_["frac"] if i_ else None)(issue_roofline(name, 1e3 / (stats_lone[name]["ms"] / stats_lone[name]["launches"]))),
-                          "issue_frac_of_mix_ceiling": (lambda i_: i_["frac_of_mix_ceiling"] if i_ else None)(issue_roofline(name, 1e3 / (stats_lone[name]["ms"] / stats_lone[name]["launches"])))}
-                         if name in stats_lone else None),
-                # every prover step by SURVEY 8(d)'s bytes over the summed HIP-event time of its kernels (per proof)
+                # every prover step by SURVEY 8(d)'s bytes over the summed LONE HIP-event time of its kernels (per proof)
                 # `frac` divides the bytes of the columns the step PROCESSED (dense wire columns: `dense_wire_columns`);
-                # `frac_incl_elided` is SURVEY 8(d)'s figure for all 270 columns over the same time (round 2's `frac`)
+                # `frac_incl_elided` is SURVEY 8(d)'s figure for all 270 columns over the same time
                 "steps": {stp: {"algorithmic_bytes": steps_b[stp], "processed_bytes": proc_b.get(stp, steps_b[stp]), "kernel_ms": ms_,
                                 "achieved_GBps": proc_b.get(stp, steps_b[stp]) / (ms_ * 1e-3) / 1e9,
                                 "frac": proc_b.get(stp, steps_b[stp]) / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                 "frac_incl_elided": steps_b[stp] / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS}
                           for stp in steps_b
-                          for ms_ in [sum(v["ms"] for k, v in stats.items() if step_of(k) == stp) / P_inflight] if ms_ > 0},
+                          for ms_ in [sum(v["ms"] for k, v in stats_lone.items() if step_of(k) == stp) / P] if ms_ > 0},
                 "dense_wire_columns": dense_w,
                 "kernels": per_kernel,
                 "counter_summaries": {"pmc": os.path.basename(newest("r*_pmc_summary.json") or "") or None,
                                       "sq": os.path.basename(newest("r*_sq_summary.json") or "") or None,
                                       "keyed_by": f"(mix, degree_bits) = {PROFILE_KEY}: null fields where this workload has no committed counter pass"},
-            }),
+            },
             "latency_ms_single_proof": single_ms,
             "latency_ms_sharded": sharded_half["latency_ms_sharded"] if sharded_half else None,
             "latency_ms_sharded_group": (sharded_half.get("group") or {}).get("latency_ms_sharded_group") if sharded_half else None,
@@ -1066,24 +1139,31 @@ def main():
             "host_witness": host,
             "pipelined": pipe,
             "phase_ms": {k: v / args.steps for k, v in sorted(phase.items())},
-            "kernel_ms_per_proof": {k: round(v["ms"] / P_inflight, 4) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])},
             "kernel_ms_per_proof_lone": {k: round(v["ms"] / P, 4) for k, v in sorted(stats_lone.items(), key=lambda kv: -kv[1]["ms"])},
             "kernel_span_ms_per_proof": {k: round(v["ms"] / P_inflight, 4) for k, v in sorted(spans.items(), key=lambda kv: -kv[1]["ms"])},
-            "kernel_ms_sum": {"gpu_time_shares": round(sum(v["ms"] for v in stats.values()) / P_inflight, 4),
+            "kernel_ms_sum": {"lone": round(sum(v["ms"] for v in stats_lone.values()) / P, 4),
                               "spans_in_flight": round(sum(v["ms"] for v in spans.values()) / P_inflight, 4),
-                              "lone": round(sum(v["ms"] for v in stats_lone.values()) / P, 4),
                               "ms_per_step_per_gpu": ms_step * (1 if sharded else world),
-                              "note": f"HIP events are per stream.  kernel_span_ms_per_proof = event spans with {S} proof(s) in flight (a span includes the time "
-                                      f"the kernel shares the chip with the other proofs' kernels: the spans sum to <= ms_per_step x {S} per GPU); "
-                                      f"kernel_ms_per_proof = span / {S} = the kernel's share of a proof's GPU time at the operating point of `value` (the shares "
-                                      f"sum to <= ms_per_step per GPU); kernel_ms_per_proof_lone = one proof at a time (the operating point of latency_ms_single_proof)"},
-            "kernel_profile": f"{P_inflight} extra proofs with {S} in flight (kernel_ms_per_proof, kernel_span_ms_per_proof, roofline) and {P} one at a time (..._lone) "
+                              "note": f"HIP events are per stream.  kernel_ms_per_proof_lone = one proof at a time (the operating point of latency_ms_single_proof; "
+                                      f"every roofline figure divides by these).  kernel_span_ms_per_proof = event spans with {S} proof(s) in flight: a span includes "
+                                      f"the time the kernel shares the chip with the other proofs' kernels (the spans sum to <= ms_per_step x {S} per GPU); "
+                                      f"spans are not durations and nothing is divided by them"},
+            "kernel_profile": f"{P} extra proofs one at a time (..._lone, roofline) and {P_inflight} with {S} in flight (kernel_span_ms_per_proof) "
                               f"after the timed region, per-launch HIP events on the library's launch streams (profile = 2: every scoped launch)",
             "device": pkg.device_info()["name"],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, d, mix if args.workload == "synth" else "sha", args.public_inputs, args.cpu_single_thread_bits)
-        print(json.dumps(out), flush=True)
+        # stdout carries ONE short line (the driver keeps 8 KB of stdout: round 4's 21 KB line came back unparsed); everything
+        # else goes to the detail file beside it
+        detail_path = args.detail or os.path.join(ROOT, "bench_detail.json")
+        try:
+            with open(detail_path, "w") as fh:
+                json.dump(out, fh, indent=1)
+        except OSError as e:
+            print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
+            detail_path = None
+        print(compact_line(out, os.path.basename(detail_path) if detail_path else None), flush=True)
     if wedged:   # a collective never came back: the line is out, leave without touching the process group again
         sys.stdout.flush()
         sys.stderr.flush()

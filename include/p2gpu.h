@@ -267,10 +267,12 @@ int p2gpu_hash_rows(const uint64_t *rows, size_t n_rows, size_t row_len, uint8_t
 /* Self-test of the device field arithmetic (the carry-chain forms of csrc/gl.hpp and the NTT's power-of-two
  * multipliers) against the portable code the host and the oracle run, on the n pairs (a[i], b[i]) of arbitrary
  * 64-bit words.  bad_out[k] = mismatches of: 0 canon, 1 add, 2 sub, 3 reduce128, 4 mul, 5 mul_add,
- * 6 x * 2^e for e = 1..95, 7 the 160-bit accumulator; 8 mul_nc, 9 mul_add_nc, 10 reduce128_nc (the congruent-word forms:
- * any u64 in, some congruent u64 out), 11 add / 12 sub with a non-canonical first operand, 13 chains of those; 14, 15
- * unused.  bad_out holds SIXTEEN words (eight until round 4).  All zero on a correct build. */
-int p2gpu_field_selftest(const uint64_t *a, const uint64_t *b, size_t n, uint64_t bad_out[16]);
+ * 6 x * 2^e for e = 1..95, 7 the 160-bit accumulator -- the EIGHT words p2gpu_field_selftest writes (its contract since
+ * round 1); p2gpu_field_selftest16 writes SIXTEEN: those, then 8 mul_nc, 9 mul_add_nc, 10 reduce128_nc (the congruent-word
+ * forms: any u64 in, some congruent u64 out), 11 add / 12 sub with a non-canonical first operand, 13 chains of those; 14, 15
+ * unused.  All zero on a correct build. */
+int p2gpu_field_selftest(const uint64_t *a, const uint64_t *b, size_t n, uint64_t bad_out[8]);
+int p2gpu_field_selftest16(const uint64_t *a, const uint64_t *b, size_t n, uint64_t bad_out[16]);
 
 const char *p2gpu_last_error(void);
 /* name/arch of the device in use, and peak numbers the bench prints */

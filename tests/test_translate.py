@@ -231,6 +231,11 @@ def test_public_parameters_are_hashed_in_circuit(pkg, orc):
     bad[3] += 1
     assert not oc.verify(proof[:-8 * 11] + b"".join(int(v).to_bytes(8, "little") for v in bad))
     oc.close()
+    # the reference keeps the parameters in BTreeSets (mod.rs:290-303): a caller's order (or a duplicate) does not matter
+    cb2 = tr.CircuitBuilderFromAcirToPlonky2()
+    cb2.translate_circuit(ops, public_parameters=[7, 3, 10, 0, 1, 9, 2, 8, 4, 6, 5, 3])
+    blob2, wires2 = cb2.build(wit)
+    assert cb2.public_inputs() == pis and np.array_equal(blob2, blob) and np.array_equal(wires2, wires)
 
 
 @pytest.mark.gpu

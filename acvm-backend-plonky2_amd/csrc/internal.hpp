@@ -31,6 +31,11 @@ constexpr int NTT_MAX_ROUNDS = 6;  // rounds of <= 3 layers in one pass: 12 laye
 struct NttPass {
   uint32_t s, a, tb, nrounds;
   uint32_t r[NTT_MAX_ROUNDS], tw_off[NTT_MAX_ROUNDS];
+  // DIT passes on full 2^12 tiles whose first round has three layers also have a "direct" form (ntt.hip ntt_dit_*_kernel):
+  // the first round straight from global memory (strided passes), the last one straight to it, its twiddles shifts only.
+  // ftw_off: offset in the plan's table of the folded twiddles of the round before the last (see fold_table_kernel)
+  bool direct = false;
+  uint32_t ftw_off = 0;
 };
 struct NttPlan {
   uint32_t d = 0;

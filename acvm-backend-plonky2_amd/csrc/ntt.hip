@@ -176,6 +176,7 @@ struct PassArgs {
   uint32_t tw_off[MAX_ROUNDS];  // offset of the round's table in ptw
   const uint32_t *colnz;        // optional [cols]: class of every column (ColHints, internal.hpp); only class 2 (dense)
                                 // columns are transformed here, the others are written by structured_fill_kernel
+  const gl_t *ftw;              // direct DIT passes: folded twiddles of the round before the last (fold_table_kernel)
 };
 
 __device__ __forceinline__ uint32_t gidx(uint32_t e, uint32_t hi_base, uint32_t lo0, uint32_t s, uint32_t tb) {
@@ -399,6 +400,239 @@ __global__ __launch_bounds__(TBC ? NTT_THREADS : 256, TBC ? NTT_MIN_WAVES : 1) v
   tile_body<DIT, INV, TBC>(lds, A, tile, col, coset0);
 }
 
+// ---- direct DIT passes (round 5) -----------------------------------------------------------------------------------------
+// The forward (coefficients -> coset values) transforms are DIT passes on full 2^12 tiles.  ntt_pass_kernel above stages a tile in
+// LDS, runs every round LDS -> registers -> LDS with a table twiddle on 7 of 8 inputs, and copies the tile out: five LDS round
+// trips and three barriers for the 12-layer pass, three and three for the 5-layer one.  Two observations remove a third of that:
+//   * The LAST round of a pass holds, in lane t, exactly the elements t | (j << beta) that lane t would copy to global memory
+//     afterwards, and (strided passes) the FIRST round's elements base | (j << tb) are what a coalesced load hands a lane: the
+//     first round runs straight from global memory, the last one stores straight to it.
+//   * The twiddle of the last round is w_{2^(s0 + r)}^(lo * brev(j)) with lo = lo' + 2^s0' * k, k the OUTPUT index of the round
+//     before: w^(lo' * brev(j)) is constant over that earlier round's butterfly group (fixed lo', fixed j = its `high` bits), so
+//     it is multiplied into that round's input twiddles (one folded table: fold_table_kernel), and what is left,
+//     w_{2^(r' + r)}^(k * brev(j)), is a power of w_64 = 2^3 -- a SHIFT -- with k uniform over the wave (k sits in bits >= 6 of the
+//     lane's group index): a scalar branch on k, then compile-time shift amounts.
+// 12-layer first pass: 5.25 -> 4.5 general products per element over the 17 layers of a 2^17-point transform together with the
+// 5-layer pass, 8 -> 5 LDS round trips, 6 -> 3 barriers.  Same values (the field result of a butterfly network does not depend on
+// how its twiddles are factored): bit-exact against the oracle and against ntt_pass_kernel (P2GPU_NTT_DIRECT=0).
+template <int E>
+__device__ __forceinline__ gl_t mul_pow2_any(gl_t x) {  // x * 2^E, 0 <= E < 192 (2^96 = -1)
+  if constexpr (E == 0) return x;
+  else if constexpr (E < 96) return mul_pow2<E>(x);
+  else if constexpr (E == 96) return gl_sub((gl_t)0, x);
+  else return gl_sub((gl_t)0, mul_pow2<E - 96>(x));
+}
+// the shift twiddles of a last round of RL layers after a round of RP layers: register j *= w_{2^(RP+RL)}^(k * brev(j))
+template <bool INV, int RL, int RP, int K>
+__device__ __forceinline__ void shift_twiddles(gl_t (&v)[1 << RL]) {
+  constexpr int UNIT = 192 >> (RP + RL);
+  static_for<1, (1 << RL)>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    constexpr int e0 = (UNIT * K * brev_c(j, RL)) % 192;
+    constexpr int e = INV ? (192 - e0) % 192 : e0;
+    v[j] = mul_pow2_any<e>(v[j]);
+  });
+}
+template <bool INV, int RL, int RP>
+__device__ __forceinline__ void shift_twiddles_k(gl_t (&v)[1 << RL], uint32_t k) {
+  static_assert(RP == 2 || RP == 3, "round before the last: two or three layers");
+  switch (__builtin_amdgcn_readfirstlane(k)) {  // k is wave-uniform: a scalar branch
+  case 0: break;
+  case 1: shift_twiddles<INV, RL, RP, 1>(v); break;
+  case 2: shift_twiddles<INV, RL, RP, 2>(v); break;
+  case 3: shift_twiddles<INV, RL, RP, 3>(v); break;
+  case 4: if constexpr (RP == 3) shift_twiddles<INV, RL, RP, 4>(v); break;
+  case 5: if constexpr (RP == 3) shift_twiddles<INV, RL, RP, 5>(v); break;
+  case 6: if constexpr (RP == 3) shift_twiddles<INV, RL, RP, 6>(v); break;
+  default: if constexpr (RP == 3) shift_twiddles<INV, RL, RP, 7>(v); break;
+  }
+}
+// A round on tile bits [beta0, beta0 + LOGR) of a 2^12 tile in LDS whose input twiddles also carry the general part of the LAST
+// round's (RL layers, the tile's top bits = this round's `high`): table row e = brev(j), then high, then lo.
+template <bool INV, int LOGR>
+__device__ __forceinline__ void round_folded(gl_t *lds, const PassArgs &A, uint32_t beta0, uint32_t rl, uint32_t lo0, const gl_t *ftw) {
+  constexpr int R = 1 << LOGR;
+  const uint32_t ngroups = 1u << (12 - LOGR);
+  const uint32_t s0 = beta0 - A.tb + A.s;
+  uint32_t lj[R];
+#pragma unroll
+  for (int j = 0; j < R; j++) lj[j] = pidx((uint32_t)j << beta0);
+  const size_t estride = (size_t)1 << (s0 + rl);
+  for (uint32_t g = threadIdx.x; g < ngroups; g += NTT_THREADS) {
+    const uint32_t low = g & ((1u << beta0) - 1), high = g >> beta0;
+    const uint32_t base = (high << (beta0 + LOGR)) | low;
+    const uint32_t lo = ((low >> A.tb) << A.s) + lo0 + (low & ((1u << A.tb) - 1));
+    gl_t v[R], t[R];
+    uint32_t li[R];
+    const uint32_t l0 = pidx(base);
+#pragma unroll
+    for (int j = 0; j < R; j++) li[j] = l0 ^ lj[j];
+#pragma unroll
+    for (int j = 0; j < R; j++) v[j] = lds[li[j]];
+    const gl_t *tp = ftw + ((size_t)high << s0) + lo;
+#pragma unroll
+    for (int e = 0; e < R; e++) {
+      t[e] = *tp;
+      tp += estride;
+    }
+    static_for<0, R>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      v[j] = gl_mul(v[j], t[brev_c(j, LOGR)]);
+    });
+    dft_regs<LOGR, 1, INV>(v);
+#pragma unroll
+    for (int j = 0; j < R; j++) lds[li[j]] = v[j];
+  }
+}
+// The last round of a pass, LDS -> registers -> global: RL layers on the tile's top bits, shift twiddles (the round before had RP
+// layers; its folded table carried the rest), then the pass's output scale.
+template <bool INV, int RL, int RP>
+__device__ __forceinline__ void round_to_global(const gl_t *lds, gl_t *dst, const PassArgs &A, uint32_t hi_base, uint32_t lo0) {
+  constexpr int R = 1 << RL;
+  constexpr uint32_t beta0 = 12 - RL;
+  uint32_t lj[R];
+#pragma unroll
+  for (int j = 0; j < R; j++) lj[j] = pidx((uint32_t)j << beta0);
+  const bool post = A.post != 1;
+#pragma unroll
+  for (uint32_t it = 0; it < ((1u << beta0) / NTT_THREADS); it++) {
+    const uint32_t g = threadIdx.x + it * NTT_THREADS;
+    gl_t v[R];
+    const uint32_t l0 = pidx(g);
+#pragma unroll
+    for (int j = 0; j < R; j++) v[j] = lds[l0 ^ lj[j]];
+    shift_twiddles_k<INV, RL, RP>(v, (g >> (beta0 - RP)) & ((1u << RP) - 1));
+    dft_regs<RL, 1, INV>(v);
+    if (post) {
+#pragma unroll
+      for (int j = 0; j < R; j++) v[j] = gl_mul(v[j], A.post);
+    }
+    const uint32_t a0 = hi_base + ((g >> A.tb) << A.s) + lo0 + (g & ((1u << A.tb) - 1));
+#pragma unroll
+    for (int j = 0; j < R; j++) dst[a0 + ((uint32_t)j << (beta0 - A.tb + A.s))] = v[j];
+  }
+}
+// block -> (tile, column, coset): the XCD-aware decode of ntt_pass_kernel
+__device__ __forceinline__ bool pass_unit(const PassArgs &A, uint32_t &tile, uint32_t &col, uint32_t &coset) {
+  const uint32_t units = A.tiles * A.cols_grid;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  coset = slot % A.cosets;
+  const uint32_t unit = (slot / A.cosets) * 8u + xcd;
+  if (unit >= units) return false;
+  tile = unit % A.tiles;
+  col = unit / A.tiles;
+  return !(A.colnz != nullptr && A.colnz[col] != 2u);
+}
+// The 12-layer first pass of a DIT transform of >= 2^12 points (s = 0, tb = 0: contiguous tiles): coalesced load (+ coset scale)
+// -> LDS | rounds on bits 0-2, 3-5, 6-8 inside each wave (no barrier; the third with the folded table) | last round -> global.
+template <bool INV>
+__global__ __launch_bounds__(NTT_THREADS, NTT_MIN_WAVES) void ntt_dit_head_kernel(PassArgs A) {
+  static_assert(NTT_THREADS == 512 && NTT_TILE_BITS == 12 && NTT_PER == 8, "direct passes: 512 lanes x 8 elements");
+  extern __shared__ gl_t lds[];
+  uint32_t tile, col, coset;
+  if (!pass_unit(A, tile, col, coset)) return;
+  const size_t n = (size_t)1 << A.d;
+  const gl_t *src = A.src + ((size_t)(A.src_single ? 0 : coset) * A.cols + col) * n;
+  gl_t *dst = A.dst + ((size_t)coset * A.cols + col) * n;
+  const gl_t *scale = A.scale ? A.scale + (size_t)(A.coset_first + coset * A.coset_stride) * n : nullptr;
+  const uint32_t tbase = tile << 12;
+  {
+    gl_t x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = src[tbase + threadIdx.x + (uint32_t)i * NTT_THREADS];
+    if (scale) {
+      gl_t sc[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) sc[i] = scale[tbase + threadIdx.x + (uint32_t)i * NTT_THREADS];
+#pragma unroll
+      for (int i = 0; i < 8; i++) x[i] = gl_mul(x[i], sc[i]);
+    }
+    const uint32_t l0 = pidx(threadIdx.x);  // (the swizzle moves bits below 5 only: + i * 512 commutes with it)
+#pragma unroll
+    for (int i = 0; i < 8; i++) lds[l0 + (uint32_t)i * NTT_THREADS] = x[i];
+  }
+  __syncthreads();
+  // rounds on bits [0, 9): wave w works on the elements whose bits [9, 12) are w in all three, and a wave's LDS operations
+  // execute in order (see wave_private in tile_body)
+  round_regs<1, INV, 3, false>(lds, A, 12, 0, 0, nullptr);
+  asm volatile("" ::: "memory");
+  round_regs<1, INV, 3, true>(lds, A, 12, 3, 0, A.ptw + A.tw_off[1]);
+  asm volatile("" ::: "memory");
+  round_folded<INV, 3>(lds, A, 6, 3, 0, A.ftw);
+  __syncthreads();
+  round_to_global<INV, 3, 3>(lds, dst, A, tbase, 0);
+}
+// A strided DIT pass of a = 3 + RM + RL layers (RM = 0: no middle round; RL = 0: a = 3, no LDS at all) on 2^12-element tiles of
+// 2^a rows x 2^tb contiguous words: first round global -> registers (its 8 elements are the rows base + j: one coalesced
+// load each), [middle round in LDS,] last round -> global.  The round before the last uses the folded table.
+template <bool INV, int RM, int RL>
+__global__ __launch_bounds__(NTT_THREADS, NTT_MIN_WAVES) void ntt_dit_strided_kernel(PassArgs A) {
+  extern __shared__ gl_t lds[];
+  uint32_t tile, col, coset;
+  if (!pass_unit(A, tile, col, coset)) return;
+  const size_t n = (size_t)1 << A.d;
+  const gl_t *src = A.src + ((size_t)(A.src_single ? 0 : coset) * A.cols + col) * n;
+  gl_t *dst = A.dst + ((size_t)coset * A.cols + col) * n;
+  const uint32_t runs = 1u << (A.s - A.tb);
+  const uint32_t hi = tile / runs, lo0 = (tile % runs) << A.tb;
+  const uint32_t hi_base = hi << (A.s + A.a);
+  {
+    // first round: group g = lane; low = its tb contiguous bits, high = the tile bits above the round
+    const uint32_t g = threadIdx.x, low = g & ((1u << A.tb) - 1), high = g >> A.tb;
+    const uint32_t base = (high << (A.tb + 3)) | low;
+    const uint32_t a0 = hi_base + ((high << 3) << A.s) + lo0 + low, lo = lo0 + low;
+    gl_t v[8], t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = src[a0 + ((uint32_t)j << A.s)];
+    constexpr bool FOLD1 = RM == 0 && RL != 0;  // the first round is the one before the last
+    if constexpr (FOLD1) {
+      const gl_t *tp = A.ftw + ((size_t)high << A.s) + lo;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        t[e] = *tp;
+        tp += (size_t)1 << (A.s + RL);
+      }
+      static_for<0, 8>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        v[j] = gl_mul(v[j], t[brev_c(j, 3)]);
+      });
+    } else {
+      const gl_t *tp = A.ptw + A.tw_off[0] + lo;
+#pragma unroll
+      for (int e = 1; e < 8; e++) {
+        t[e] = *tp;
+        tp += (size_t)1 << A.s;
+      }
+      static_for<1, 8>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        v[j] = gl_mul(v[j], t[brev_c(j, 3)]);
+      });
+    }
+    dft_regs<3, 1, INV>(v);
+    if constexpr (RL == 0) {
+      if (A.post != 1) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = gl_mul(v[j], A.post);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) dst[a0 + ((uint32_t)j << A.s)] = v[j];
+      return;
+    } else {
+      const uint32_t l0 = pidx(base);
+#pragma unroll
+      for (int j = 0; j < 8; j++) lds[l0 ^ pidx((uint32_t)j << A.tb)] = v[j];
+    }
+  }
+  if constexpr (RL != 0) {
+    __syncthreads();
+    if constexpr (RM != 0) {
+      round_folded<INV, RM>(lds, A, A.tb + 3, RL, lo0, A.ftw);
+      __syncthreads();
+    }
+    round_to_global<INV, RL, (RM != 0 ? RM : 3)>(lds, dst, A, hi_base, lo0);
+  }
+}
+
 static inline size_t lds_bytes(uint32_t TB) { return std::max<size_t>((size_t)1 << TB, 256) * sizeof(gl_t); }  // no padding: pidx() is a permutation of every 256-element block
 
 // ---- plan -----------------------------------------------------------------------
@@ -409,6 +643,22 @@ __global__ void round_table_kernel(gl_t *out, gl_t root_n, uint32_t d, uint32_t 
   if (i >= cnt) return;
   const uint32_t e = i / M + 1, lo = i % M;
   out[i] = gl_pow(root_n, ((uint64_t)lo * e) << (d - s0 - r));
+}
+
+// folded twiddles of a round of r layers at s0 whose inputs also take the general part of the next (last, rl layers) round's:
+// F[(e * 2^rl + J) * M + lo] = w_{2^(s0+r)}^(lo e) * w_{2^(s0+r+rl)}^(lo brev_rl(J)), M = 2^s0, e < 2^r, J < 2^rl
+__global__ void fold_table_kernel(gl_t *out, gl_t root_n, uint32_t d, uint32_t s0, uint32_t r, uint32_t rl) {
+  const uint32_t M = 1u << s0, cnt = (1u << (r + rl)) * M;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  const uint32_t lo = i % M, J = (i / M) & ((1u << rl) - 1), e = i >> (s0 + rl);
+  const uint64_t ex = (((uint64_t)lo * e) << (d - s0 - r)) + (((uint64_t)lo * bitrev32(J, rl)) << (d - s0 - r - rl));
+  out[i] = gl_pow(root_n, ex);
+}
+// P2GPU_NTT_DIRECT=0: every pass through ntt_pass_kernel (A/B measurements, and the reference the direct kernels are tested against)
+static bool direct_on() {
+  static const bool on = [] { const char *e = getenv("P2GPU_NTT_DIRECT"); return !(e && *e == '0'); }();
+  return on;
 }
 
 static void split_rounds(uint32_t a, std::vector<uint32_t> &r) {
@@ -474,6 +724,18 @@ NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse) {
       if (s0 > 0) total += (size_t)((1u << rr[i]) - 1) << s0;
       beta += rr[i];
     }
+    // the direct form (DIT, full tiles): the 12-layer head [3,3,3,3], strided passes [3], [3,2], [3,3], [3,2,2], [3,3,2], [3,3,3]
+    if (dit && !inverse && NTT_TILE_BITS == 12 && NTT_PER == 8 && ps.a + ps.tb == 12 && np.r[0] == 3 &&
+        (ps.s == 0 ? (ps.a == 12) : (ps.a == 3 || (ps.a >= 5 && ps.a <= 9)))) {
+      np.direct = true;
+      if (np.nrounds >= 2) {
+        const uint32_t q = np.nrounds - 2, rl = np.r[np.nrounds - 1];  // the round before the last
+        uint32_t bq = ps.tb;
+        for (uint32_t i = 0; i < q; i++) bq += np.r[i];
+        np.ftw_off = (uint32_t)total;
+        total += (size_t)1 << (np.r[q] + rl + (bq - ps.tb + ps.s));
+      }
+    }
     p->passes.push_back(np);
   }
   p->table_len = total;
@@ -494,6 +756,13 @@ NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse) {
                              s0, np.r[i]);
         }
         beta += np.r[i];
+      }
+      if (np.direct && np.nrounds >= 2) {
+        const uint32_t q = np.nrounds - 2, rl = np.r[np.nrounds - 1];
+        uint32_t bq = np.tb;
+        for (uint32_t i = 0; i < q; i++) bq += np.r[i];
+        const uint32_t s0 = bq - np.tb + np.s, cnt = 1u << (np.r[q] + rl + s0);
+        hipLaunchKernelGGL(fold_table_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, p->ptw + np.ftw_off, root, d, s0, np.r[q], rl);
       }
     }
   }
@@ -597,6 +866,7 @@ static void fill_pass_args(PassArgs &A, const NttPlan *plan, size_t i, const gl_
   A.coset_stride = cm.stride;
   A.nrounds = ps.nrounds;
   A.colnz = colnz;
+  A.ftw = ps.direct ? plan->ptw + ps.ftw_off : nullptr;
   for (int k = 0; k < MAX_ROUNDS; k++) { A.r[k] = ps.r[k]; A.tw_off[k] = ps.tw_off[k]; }
   A.tiles = 1u << (plan->d - (A.a + A.tb));
   A.cols_grid = cols; A.cosets = cosets;
@@ -626,8 +896,31 @@ static void ntt_passes(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_
     // expected HBM bytes: every output element is written once; the input is read once per element, except
     // that the cosets of one (tile, column) share their source through one XCD's L2 (first LDE pass)
     const double bytes = 8.0 * (double)cols * ((size_t)1 << d) * (cosets + (A.src_single ? 1.0 : (double)cosets));
-    ProfScope psx(pass_kernel_name(plan, TB == NTT_TILE_BITS), bytes);
     const size_t lb = lds_bytes(TB);
+    if (plan->passes[i].direct && direct_on()) {
+      const NttPass &ps = plan->passes[i];
+      const uint32_t rm = ps.nrounds == 3 ? ps.r[1] : 0, rl = ps.nrounds >= 2 ? ps.r[ps.nrounds - 1] : 0;
+      // (profile names = rocprofv3's demangled symbols)
+      if (ps.s == 0) {
+        ProfScope psd("ntt_dit_head_kernel<false>", bytes);
+        hipLaunchKernelGGL((ntt_dit_head_kernel<false>), grid, dim3(NTT_THREADS), lb, st, A);
+      } else {
+#define P2_STRIDED(RM, RL)                                                                                        \
+  do {                                                                                                            \
+    ProfScope psd("ntt_dit_strided_kernel<false, " #RM ", " #RL ">", bytes);                                      \
+    hipLaunchKernelGGL((ntt_dit_strided_kernel<false, RM, RL>), grid, dim3(NTT_THREADS), (RL) ? lb : 0, st, A);    \
+  } while (0)
+        if (rm == 0 && rl == 0) P2_STRIDED(0, 0);
+        else if (rm == 0 && rl == 2) P2_STRIDED(0, 2);
+        else if (rm == 0 && rl == 3) P2_STRIDED(0, 3);
+        else if (rm == 2 && rl == 2) P2_STRIDED(2, 2);
+        else if (rm == 3 && rl == 2) P2_STRIDED(3, 2);
+        else P2_STRIDED(3, 3);
+#undef P2_STRIDED
+      }
+      continue;
+    }
+    ProfScope psx(pass_kernel_name(plan, TB == NTT_TILE_BITS), bytes);
 #define P2_LAUNCH(DITV, INVV)                                                                                \
   do {                                                                                                       \
     if (TB == NTT_TILE_BITS) hipLaunchKernelGGL((ntt_pass_kernel<DITV, INVV, NTT_TILE_BITS>), grid, dim3(NTT_THREADS), lb, st, A);           \

@@ -53,6 +53,9 @@ void batch_from_values(batch_t *b, const gl_t *vals, size_t ncols, unsigned d, u
 void batch_from_coeffs(batch_t *b, const gl_t *coeffs, size_t ncols, unsigned d, unsigned rate_bits, unsigned cap_h);
 void batch_free(batch_t *b);
 void *big_malloc(size_t bytes); /* malloc; >= 4 MB: 2 MB-aligned + MADV_HUGEPAGE (free() releases it) */
+/* big_malloc, or -- ORC_SPILL_DIR set and the buffer >= ORC_SPILL_MIN_GB -- a file-backed mapping there; spill_free releases either */
+void *spill_malloc(size_t bytes);
+void spill_free(void *p);
 /* get_lde_values(i, step=1): pointer to the ncols values at natural LDE index i */
 static inline const gl_t *batch_lde_row(const batch_t *b, size_t i) {
   return b->leaves + bitrev(i, b->d + b->rate_bits) * b->ncols;

@@ -269,8 +269,11 @@ int orc_prove(const orc_circuit *oc, const uint64_t *wires, const uint64_t *pis,
     {
       gl_t *terms = (gl_t *)malloc(sizeof(gl_t) * (nterms + 2 * NGC + 8));
       gl_t *scratch = terms + nterms;
+      /* rows are independent: walked in LEAF order (i = bitrev(leaf)), so that the three big row-major LDE buffers are read
+       * front to back (the wires' one may be a 31 GB file mapping, poly.c spill_malloc); the results land at their natural index */
 #pragma omp for schedule(static)
-      for (size_t i = 0; i < N; i++) {
+      for (size_t leaf = 0; leaf < N; leaf++) {
+        const size_t i = bitrev(leaf, lgN);
         gl_t x = pts[i];
         const gl_t *crow = batch_lde_row(&c->cs, i);
         const gl_t *wrow = batch_lde_row(&wb, i);

@@ -6,6 +6,10 @@ tests demand bit-exactness at 2^20 / 2^22 LDE rows without running the oracle on
 are NOT reference outputs -- the reference prover cannot run here.  Run from the
 repo root (the --large pass takes ~10 min and ~25 GB on 8 cores):
     python tests/golden/gen_proof_digests.py [--large]
+--xlarge adds BASELINE configs[4] (2^24 LDE rows) to proof_digests_large.json without redoing the entries it holds.  The oracle's
+row-major LDE of the wires is 31 GB there (11 GB for constants/sigmas) on a 62 GB build box: run it with
+    ORC_SPILL_DIR=/tmp/orc_spill python tests/golden/gen_proof_digests.py --xlarge
+(oracle/poly.c spill_malloc: those two buffers become file mappings; ~25 GB of RAM, ~45 GB of disk, ~20 min on 8 cores).
 """
 import hashlib
 import json
@@ -25,6 +29,9 @@ CASES = [(5, "arith", 1, 0), (6, "sha", 2, 0), (7, "ecdsa", 3, 0), (9, "ecdsa", 
 # BASELINE.json configs[2] (SHA256 ~2^20 LDE rows: the bench workload, seed 1), the same size with every
 # gate kind and with public inputs (PoseidonGate), and configs[3] (EcdsaSecp256k1 ~2^22 LDE rows)
 LARGE = [(17, "sha", 1, 0), (17, "ecdsa", 1, 0), (17, "sha", 3, 4), (19, "ecdsa", 2, 0)]
+# BASELINE.json configs[4] (zk-grammar ~2^24 LDE rows: the `grammar` mix -- arithmetic + SHA bit logic + RandomAccess /
+# memory rows), and the bench workload's mix at the same size
+XLARGE = [(21, "grammar", 1, 0), (21, "sha", 1, 0)]
 # hand-written ACIR-equivalents (BASELINE configs[0]: the fibonacci example program)
 HAND = {"fibonacci": mini_builder.fibonacci, "quadratic_example": mini_builder.quadratic_example}
 SHA256_IV = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
@@ -80,6 +87,16 @@ def main():
     entry.build()
     pkg, orc = entry.load_package(), entry.load_oracle()
     gold = os.path.join(ROOT, "tests", "golden")
+    if "--xlarge" in sys.argv:
+        path = os.path.join(gold, "proof_digests_large.json")
+        have = json.load(open(path))
+        for case in XLARGE:
+            if any((g["degree_bits"], g["mix"], g["seed"], g["public_inputs"]) == case for g in have):
+                continue
+            have += synth_cases(pkg, orc, [case])
+            with open(path, "w") as f:
+                json.dump(have, f, indent=1)
+        return
     if "--large" in sys.argv:
         with open(os.path.join(gold, "proof_digests_large.json"), "w") as f:
             json.dump(synth_cases(pkg, orc, LARGE), f, indent=1)

@@ -114,6 +114,49 @@ def test_two_pass_transforms_ragged_column_counts(gpu):
     assert r.returncode == 0 and "fused-stage-ok" in r.stdout, r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("d", [12, 15, 17, 18, 19, 20])
+def test_direct_dit_passes_match_oracle(pkg, orc, gpu, d):
+    """The direct DIT passes of round 5 (ntt.hip ntt_dit_head_kernel / ntt_dit_strided_kernel: first round from global memory, last
+    round to it with shift twiddles, folded table in between), one size per shape of the strided pass -- 12: head only; 15: [3];
+    17: [3,2]; 18: [3,3]; 19: [3,2,2]; 20: [3,3,2] (21 = [3,3,3] and 22 = two strided passes: test_deep_transforms) -- every word of
+    the coset LDE against the oracle, three columns (one of edge words, one zero)."""
+    v = _rand((3, 1 << d), 100 + d)
+    v[0, :8] = [P - 1, 0, 1, P - 2, 1 << 32, (1 << 32) - 1, P - (1 << 32), 2]
+    v[2, :] = 0
+    rate = 3 if d <= 17 else 1
+    lde = pkg.lde_batch(v, rate)
+    assert np.array_equal(lde, np.stack([orc.coset_lde(r, rate) for r in v]))
+
+
+def test_direct_and_generic_passes_agree(gpu):
+    """P2GPU_NTT_DIRECT=0 sends every pass through ntt_pass_kernel (the round 1-4 path): same LDE words and same proof bytes as the
+    default build's direct passes, in a process of its own (the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, {root!r})
+import __graft_entry__ as ge
+pkg = ge.load_package()
+rng = np.random.default_rng(77)
+P = 0xFFFFFFFF00000001
+for d in (12, 15, 17, 19, 21):
+    v = rng.integers(0, P, size=(2, 1 << d), dtype=np.uint64)
+    print("LDE", d, hashlib.sha256(pkg.lde_batch(v, 3 if d <= 17 else 1).tobytes()).hexdigest())
+blob, wires = pkg.make_circuit(14, "ecdsa", 5)
+print("PROOF", hashlib.sha256(pkg.CircuitData(blob).prove(wires).to_bytes()).hexdigest())
+""".format(root=root)
+    outs = []
+    for direct in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, P2GPU_NTT_DIRECT=direct), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("LDE", "PROOF"))])
+    assert len(outs[0]) == 6 and outs[0] == outs[1]
+
+
 @pytest.mark.parametrize("d", [21, 22])
 def test_deep_transforms(pkg, orc, gpu, d):
     """2^21 points: 12 + 9 layers (one strided pass with 64-byte runs); 2^22: 12 + 5 + 5 (two strided

@@ -104,8 +104,10 @@ struct VirtCols {
 };
 // leaf digests of an LDE batch: lde [cosets][cols][n] -> dig [cosets][n]
 // prc: the handle's Poseidon round constants in device memory selects PoseidonHash; nullptr = KeccakHash<25>
-void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig, const gl_t *prc = nullptr,
-                     const VirtCols *virt = nullptr);
+// lvl1 / lvl2 (optional): storage of the tree levels with n/2 and n/4 nodes per coset; the return value says how many levels
+// above the leaves the launch has also built (0 or 2: merkle.hip hash_lde_leaves_kf_kernel<V, 2>)
+uint32_t hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig, const gl_t *prc = nullptr,
+                         const VirtCols *virt = nullptr, dig_t *lvl1 = nullptr, dig_t *lvl2 = nullptr);
 // row-major rows (stage-level operator)
 void hash_rows(hipStream_t st, const gl_t *rows, size_t n_rows, uint32_t row_len, dig_t *dig);
 // FRI step leaves: vals [cosets][2][npc] (ext coordinates), leaf = 16 ext values; dig [cosets][npc/16]

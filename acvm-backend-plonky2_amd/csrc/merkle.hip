@@ -240,66 +240,8 @@ __device__ __forceinline__ dig_t kf_digest() {
   (void)h3;
   return dg;
 }
-// same contract as hash_lde_leaves_kernel<0, V>; rows of <= 3 elements (copied, not hashed) never come here
-template <bool V>
-__global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void hash_lde_leaves_kf_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
-                                                                                   dig_t *__restrict__ dig, const VirtCols v) {
-  const size_t n = (size_t)1 << d;
-  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t c = blockIdx.y;
-  if (k >= n) return;
-  const gl_t *base = lde + (size_t)c * cols * n + k;
-  gl_t Lk = 0;
-  if constexpr (V) Lk = v.basis ? v.basis[(size_t)(v.coset_first + c * v.coset_stride) * n + k] : (gl_t)0;
-  auto get = [&](uint32_t i) -> gl_t {
-    if constexpr (V) return virt_get(v, i, Lk, base, n);
-    else return base[(size_t)i * n];
-  };
-  kf_zero();
-  if constexpr (!V) {
-    // every word is a load: software pipeline -- the 17 loads of block b + 1 are issued before the permutation of block b and
-    // land under its 4 309 instructions (the array lives in hipcc's registers across the asm block; kf_check.py watches them)
-    uint64_t x[17];
-    // words of the rate block at `off`; the last block is ragged: rem < 17 words, then the 0x01 of the padding, then zeros
-    auto load_block = [&](uint32_t off) {
-      const uint32_t rem = cols - off;
-#pragma unroll
-#ifdef P2_KF_NOLOAD  /* timing experiment only (scratch/): what the kernel costs without its memory traffic */
-      for (int w = 0; w < 17; w++) x[w] = (uint32_t)w < rem ? (uint64_t)(k + off + w) : ((uint32_t)w == rem ? (uint64_t)1 : (uint64_t)0);
-#else
-      for (int w = 0; w < 17; w++) x[w] = (uint32_t)w < rem ? base[(size_t)(off + w) * n] : ((uint32_t)w == rem ? (uint64_t)1 : (uint64_t)0);
-#endif
-    };
-    load_block(0);
-    for (uint32_t off = 0;;) {
-      const bool last = cols - off < 17;
-      kf_for<0, 17>([&](auto wc) {
-        constexpr int w = decltype(wc)::value;
-        const uint64_t xw = x[w];
-        const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
-        P2_KF_XOR(w, lo, hi);
-      });
-      if (last) P2_KF_XOR(16, 0u, 0x80000000u);
-      off += 17;
-      if (!last) load_block(off);
-      P2_KECCAK_FIXED_PERMUTE();  // (the one call site of this kernel)
-      if (last) break;
-    }
-  } else {
-    for (uint32_t off = 0;; off += 17) {
-      const uint32_t rem = cols - off;
-      kf_absorb<V>(off, rem, get);
-      P2_KECCAK_FIXED_PERMUTE();
-      if (rem < 17) break;
-    }
-  }
-  dig[(size_t)c * n + k] = kf_digest();
-}
-// KeccakHash<25>::two_to_one (keccak_two_to_one of keccak.hpp) on the fixed registers: Keccak-256(left[25] || right[25])[..25].
-// PH = code-placement phase of the permutation block (keccak_fixed.inc): 1 for levels with many nodes, 0 when a SIMD holds a
-// lone wave (the tails, the small levels).
-template <int PH>
-__device__ __forceinline__ dig_t kf_two_to_one(const dig_t &l, const dig_t &r) {
+// state words 0..24 <- the padded 50-byte message left[25] || right[25] of KeccakHash<25>::two_to_one (the permutation follows)
+__device__ __forceinline__ void kf_set_two_to_one(const dig_t &l, const dig_t &r) {
   uint64_t w[7];
   w[0] = l.w[0];
   w[1] = l.w[1];
@@ -318,6 +260,109 @@ __device__ __forceinline__ dig_t kf_two_to_one(const dig_t &l, const dig_t &r) {
     constexpr int i = decltype(ic)::value;
     P2_KF_SET(i, 0u, (i == 16 ? 0x80000000u : 0u));
   });
+}
+// same contract as hash_lde_leaves_kernel<0, V>; rows of <= 3 elements (copied, not hashed) never come here.
+// LV = 2 (round 5): the block also builds the first TWO tree levels over its leaves.  Level l pairs nodes k and k + n / 2^l of a
+// coset, so the four waves of a block take the leaves k + g * n/4 (g = wave; 64 neighbouring k: every column read is still one
+// 512 B access): level 1 node k = H(leaf k, leaf k + n/2) is wave g < 2's own digest with wave g + 2's, level 2 node k is wave
+// 0's level-1 digest with wave 1's -- partners pass through LDS, a wave whose digests have been handed on ends (s_barrier
+// counts surviving waves only).  Three quarters of a tree's node hashes without a launch of their own, their children never
+// read back from memory.  The whole chain runs through ONE permutation call site (two 34 KB copies would not share the 64 KB
+// instruction cache): a loop whose body is "prepare the state | permute | if a hash is complete, store it and pick the next".
+template <bool V, int LV>
+__global__ __launch_bounds__(256) P2_KF_KERNEL_ATTR void hash_lde_leaves_kf_kernel(const gl_t *__restrict__ lde, uint32_t cols, uint32_t d,
+                                                                                   dig_t *__restrict__ dig, dig_t *__restrict__ lvl1,
+                                                                                   dig_t *__restrict__ lvl2, const VirtCols v) {
+  __shared__ dig_t xch1[LV ? 2 : 1][64], xch2[64];
+  const size_t n = (size_t)1 << d;
+  const uint32_t g = threadIdx.x >> 6, t = threadIdx.x & 63u;
+  const size_t k = LV ? (size_t)blockIdx.x * 64 + t + (size_t)g * (n >> 2) : (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = blockIdx.y;
+  if (!LV && k >= n) return;
+  const gl_t *base = lde + (size_t)c * cols * n + k;
+  gl_t Lk = 0;
+  if constexpr (V) Lk = v.basis ? v.basis[(size_t)(v.coset_first + c * v.coset_stride) * n + k] : (gl_t)0;
+  auto get = [&](uint32_t i) -> gl_t {
+    if constexpr (V) return virt_get(v, i, Lk, base, n);
+    else return base[(size_t)i * n];
+  };
+  kf_zero();
+  // every word of the plain variant is a load: software pipeline -- the 17 loads of block b + 1 are issued before the permutation
+  // of block b and land under its 4 309 instructions (the array lives in hipcc's registers across the asm block; kf_check.py
+  // watches them)
+  uint64_t x[V ? 1 : 17];
+  // words of the rate block at `off`; the last block is ragged: rem < 17 words, then the 0x01 of the padding, then zeros
+  auto load_block = [&](uint32_t off) {
+    if constexpr (!V) {
+      const uint32_t rem = cols - off;
+#pragma unroll
+#ifdef P2_KF_NOLOAD  /* timing experiment only (scratch/): what the kernel costs without its memory traffic */
+      for (int w = 0; w < 17; w++) x[w] = (uint32_t)w < rem ? (uint64_t)(k + off + w) : ((uint32_t)w == rem ? (uint64_t)1 : (uint64_t)0);
+#else
+      for (int w = 0; w < 17; w++) x[w] = (uint32_t)w < rem ? base[(size_t)(off + w) * n] : ((uint32_t)w == rem ? (uint64_t)1 : (uint64_t)0);
+#endif
+    }
+  };
+  load_block(0);
+  uint32_t off = 0, stage = 0;  // stage 0: the leaf's sponge; 1, 2: the node of that tree level
+  for (;;) {
+    bool complete = true;
+    // (opaque to the loop optimiser: with `off` a recognisable induction variable hipcc keeps seventeen 64-bit column pointers
+    // live across the permutation instead of forming them at the loads -- 30 spilled dwords)
+    off = __builtin_amdgcn_readfirstlane(off);
+    if (stage == 0) {
+      const uint32_t rem = cols - off;
+      complete = rem < 17;
+      if constexpr (!V) {
+        kf_for<0, 17>([&](auto wc) {
+          constexpr int w = decltype(wc)::value;
+          const uint64_t xw = x[w];
+          const uint32_t lo = (uint32_t)xw, hi = (uint32_t)(xw >> 32);
+          P2_KF_XOR(w, lo, hi);
+        });
+        if (complete) P2_KF_XOR(16, 0u, 0x80000000u);
+        off += 17;
+        if (!complete) load_block(off);
+      } else {
+        kf_absorb<true>(off, rem, get);
+        off += 17;
+      }
+    }
+    P2_KECCAK_FIXED_PERMUTE();  // (the one call site of this kernel)
+    if (!complete) continue;
+    const dig_t dg = kf_digest();
+    if (stage == 0) dig[(size_t)c * n + k] = dg;
+    else if (stage == 1) lvl1[(size_t)c * (n >> 1) + k] = dg;
+    else lvl2[(size_t)c * (n >> 2) + k] = dg;
+    if (stage == (uint32_t)LV) break;
+    dig_t r;
+    if (stage == 0) {
+      if (g >= 2) xch1[g & 1][t] = dg;
+      __syncthreads();
+      if (g >= 2) break;
+      r = xch1[g & 1][t];
+    } else {
+      if (g == 1) xch2[t] = dg;
+      __syncthreads();  // (waves 2 and 3 have ended)
+      if (g == 1) break;
+      r = xch2[t];
+    }
+    kf_set_two_to_one(dg, r);
+    if constexpr (!V) {
+      // the prefetch array is dead from here on; saying so (constants, not the last block's words, go round the loop) lets
+      // hipcc give its registers to the node's words above -- otherwise 22 dwords spill
+#pragma unroll
+      for (int w = 0; w < 17; w++) x[w] = 0;
+    }
+    stage++;
+  }
+}
+// KeccakHash<25>::two_to_one (keccak_two_to_one of keccak.hpp) on the fixed registers: Keccak-256(left[25] || right[25])[..25].
+// PH = code-placement phase of the permutation block (keccak_fixed.inc): 1 for levels with many nodes, 0 when a SIMD holds a
+// lone wave (the tails, the small levels).
+template <int PH>
+__device__ __forceinline__ dig_t kf_two_to_one(const dig_t &l, const dig_t &r) {
+  kf_set_two_to_one(l, r);
   if constexpr (PH == 0) P2_KECCAK_FIXED_PERMUTE_PH(0);  // (the macro stringifies its argument: literals only)
   else P2_KECCAK_FIXED_PERMUTE_PH(1);
   return kf_digest();
@@ -662,27 +707,45 @@ bool merkle_tail(hipStream_t st, dig_t *lvl, uint32_t cosets, uint32_t m, uint32
   }
 }
 
-void hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig, const gl_t *prc,
-                     const VirtCols *virt) {
+// P2GPU_LEAF_LEVELS=0: the leaf kernels leave every tree level to merkle_level / merkle_tail (A/B measurements)
+static bool leaf_levels_on() {
+  static const bool on = [] { const char *e = getenv("P2GPU_LEAF_LEVELS"); return !(e && *e == '0'); }();
+  return on;
+}
+// Returns how many tree levels above the leaf digests the launch has ALSO built (0 or 2): lvl1 / lvl2 = storage of the levels with
+// n/2 and n/4 nodes per coset ([cosets][n/2], [cosets][n/4]; nullptr: leaves only).
+uint32_t hash_lde_leaves(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, dig_t *dig, const gl_t *prc,
+                         const VirtCols *virt, dig_t *lvl1, dig_t *lvl2) {
   size_t n = (size_t)1 << d;
   uint32_t threads = n >= 256 ? 256 : 64;
   // Keccak, a hashed leaf (more than 3 elements) and full 256-lane blocks: the fixed-register sponge (profile names = the
   // symbols rocprofv3 shows)
   const bool kf = !prc && cols * 8 > 25 && n >= 256;
-  if (virt && virt->cls && virt->first < cols) {  // the wires of a proof with unmaterialised columns (same digests)
-    ProfScope ps(prc ? "hash_lde_leaves_kernel<1, true>" : (kf ? "hash_lde_leaves_kf_kernel<true>" : "hash_lde_leaves_kernel<0, true>"),
-                 (8.0 * cols + 32.0) * cosets * (double)n);
-    if (prc) hipLaunchKernelGGL((hash_lde_leaves_kernel<1, true>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, *virt);
-    else if (kf) hipLaunchKernelGGL((hash_lde_leaves_kf_kernel<true>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, *virt);
-    else hipLaunchKernelGGL((hash_lde_leaves_kernel<0, true>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, *virt);
-    return;
+  // ... only where it measured faster (profiles/r05_tree_levels.md, 2^20 rows, lone proof): the wires tree of a witness with
+  // unmaterialised columns (14 permutations per leaf; grouped-load sponge): 1603 us against 1545 + 57 + 31 for leaves + two level
+  // launches.  Not the 2-block leaves of Z / partial products (302 vs 300) or the 1-block leaves of the quotient (204 vs 185:
+  // after one permutation half, then three quarters of a block's waves have nothing left to do), and not a dense wires tree,
+  // whose prefetching sponge <false, 0> cannot spare the registers (1615 vs 1483 + 59 + 32 through the grouped-load form)
+  const bool virt_on = virt && virt->cls && virt->first < cols;
+  const bool lv2 = kf && virt_on && lvl1 != nullptr && lvl2 != nullptr && cols > 3 * 17 && leaf_levels_on();
+  const double node_bytes = lv2 ? 96.0 * cosets * (double)(n / 2 + n / 4) : 0.0;
+  const dim3 grid((uint32_t)((n + threads - 1) / threads), cosets);
+  if (virt_on) {  // the wires of a proof with unmaterialised columns (same digests)
+    ProfScope ps(prc ? "hash_lde_leaves_kernel<1, true>" : (kf ? (lv2 ? "hash_lde_leaves_kf_kernel<true, 2>" : "hash_lde_leaves_kf_kernel<true, 0>") : "hash_lde_leaves_kernel<0, true>"),
+                 (8.0 * cols + 32.0) * cosets * (double)n + node_bytes);
+    if (prc) hipLaunchKernelGGL((hash_lde_leaves_kernel<1, true>), grid, dim3(threads), 0, st, lde, cols, d, dig, prc, *virt);
+    else if (lv2) hipLaunchKernelGGL((hash_lde_leaves_kf_kernel<true, 2>), grid, dim3(threads), 0, st, lde, cols, d, dig, lvl1, lvl2, *virt);
+    else if (kf) hipLaunchKernelGGL((hash_lde_leaves_kf_kernel<true, 0>), grid, dim3(threads), 0, st, lde, cols, d, dig, lvl1, lvl2, *virt);
+    else hipLaunchKernelGGL((hash_lde_leaves_kernel<0, true>), grid, dim3(threads), 0, st, lde, cols, d, dig, prc, *virt);
+    return lv2 ? 2u : 0u;
   }
   // same spelling as rocprofv3's demangled names (<0> Keccak, <1> Poseidon), so the bench line and profiles/ agree
-  ProfScope ps(prc ? "hash_lde_leaves_kernel<1, false>" : (kf ? "hash_lde_leaves_kf_kernel<false>" : "hash_lde_leaves_kernel<0, false>"),
-               (8.0 * cols + 32.0) * cosets * (double)n);
-  if (prc) hipLaunchKernelGGL((hash_lde_leaves_kernel<1, false>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, VirtCols());
-  else if (kf) hipLaunchKernelGGL((hash_lde_leaves_kf_kernel<false>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, VirtCols());
-  else hipLaunchKernelGGL((hash_lde_leaves_kernel<0, false>), dim3((n + threads - 1) / threads, cosets), dim3(threads), 0, st, lde, cols, d, dig, prc, VirtCols());
+  ProfScope ps(prc ? "hash_lde_leaves_kernel<1, false>" : (kf ? "hash_lde_leaves_kf_kernel<false, 0>" : "hash_lde_leaves_kernel<0, false>"),
+               (8.0 * cols + 32.0) * cosets * (double)n + node_bytes);
+  if (prc) hipLaunchKernelGGL((hash_lde_leaves_kernel<1, false>), grid, dim3(threads), 0, st, lde, cols, d, dig, prc, VirtCols());
+  else if (kf) hipLaunchKernelGGL((hash_lde_leaves_kf_kernel<false, 0>), grid, dim3(threads), 0, st, lde, cols, d, dig, lvl1, lvl2, VirtCols());
+  else hipLaunchKernelGGL((hash_lde_leaves_kernel<0, false>), grid, dim3(threads), 0, st, lde, cols, d, dig, prc, VirtCols());
+  return lv2 ? 2u : 0u;
 }
 void hash_lde_absorb(hipStream_t st, const gl_t *lde, uint32_t cols, uint32_t d, uint32_t cosets, uint32_t blk0,
                      uint32_t nblk, bool first, bool last, uint64_t *state, dig_t *dig, const VirtCols *virt) {

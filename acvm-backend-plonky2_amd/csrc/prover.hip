@@ -382,9 +382,10 @@ int wait_stream(p2gpu_circuit *c) {
   return 0;
 }
 
-int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
+// levels_done: tree levels above the leaf digests that are in place already (the leaf-hash launch builds two: merkle.hip)
+int tree_build(p2gpu_circuit *c, Batch &b, size_t m0, uint32_t levels_done = 0) {
   const uint32_t C = c->C, CL = b.ncl;
-  size_t m = m0;
+  size_t m = m0 >> levels_done;
   const size_t cap_target = ((size_t)1 << c->cap_h) >> c->rate_bits;
   // a tree every rank holds completely (constants/sigmas, FRI steps >= 1) needs no exchange -- except in
   // the one-rank plumbing test, where every tree goes through the transport
@@ -393,7 +394,7 @@ int tree_build(p2gpu_circuit *c, Batch &b, size_t m0) {
   // copy kernel between the last level and the transcript's sync
   dig_t *mirror = local && m0 > cap_target ? c->pin.take<dig_t>(C * cap_target) : nullptr;
   bool mirrored = false;
-  for (size_t l = 1; l < b.level_off.size(); l++) {
+  for (size_t l = 1 + levels_done; l < b.level_off.size(); l++) {
     // the rest of the tree in merkle_tail: a few launches of several levels each (Keccak), or one (Poseidon)
     const size_t from = merkle_tail_from(hprc(c));
     if ((size_t)CL * (m >> 1) <= from) {
@@ -471,7 +472,14 @@ VirtCols batch_virt(const p2gpu_circuit *c, const Batch &b) {
   v.coset_stride = b.cm.stride;
   return v;
 }
+// leaf digests of a batch (+ the first two tree levels when the layout has them: the return value)
+uint32_t leaf_hash(p2gpu_circuit *c, Batch &b, const VirtCols &v) {
+  const bool two = b.level_off.size() >= 3;  // levels with n/2 and n/4 nodes per coset exist
+  return hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p, hprc(c), &v, two ? b.dig.p + b.level_off[1] : nullptr,
+                         two ? b.dig.p + b.level_off[2] : nullptr);
+}
 int batch_commit_from_coeffs(p2gpu_circuit *c, Batch &b) {
+  uint32_t lv = 0;
   {
     const uint32_t *nz = batch_colnz(c, b);
     const ColHints h = nz ? wire_hints(c, 0, true) : ColHints();
@@ -480,17 +488,17 @@ int batch_commit_from_coeffs(p2gpu_circuit *c, Batch &b) {
   }
   {
     const VirtCols v = batch_virt(c, b);
-    hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p, hprc(c), &v);
+    lv = leaf_hash(c, b, v);
   }
   TRACE(c, "  lde + leaf hash");
-  return tree_build(c, b, c->n);
+  return tree_build(c, b, c->n, lv);
 }
 // hash + tree of a batch whose LDE is already in place
 int batch_commit_from_lde(p2gpu_circuit *c, Batch &b) {
   const VirtCols v = batch_virt(c, b);
-  hash_lde_leaves(c->stream, b.lde.p, b.cols, c->d, b.ncl, b.dig.p, hprc(c), &v);
+  const uint32_t lv = leaf_hash(c, b, v);
   TRACE(c, "  leaf hash");
-  return tree_build(c, b, c->n);
+  return tree_build(c, b, c->n, lv);
 }
 int batch_commit_from_values(p2gpu_circuit *c, Batch &b, const gl_t *vals_dev) {
   if (&b == &c->wires && c->wires_ntt_done) return c->wires_hash_done ? tree_build(c, b, c->n) : batch_commit_from_lde(c, b);

@@ -128,9 +128,11 @@ def test_direct_dit_passes_match_oracle(pkg, orc, gpu, d):
     assert np.array_equal(lde, np.stack([orc.coset_lde(r, rate) for r in v]))
 
 
-def test_direct_and_generic_passes_agree(gpu):
-    """P2GPU_NTT_DIRECT=0 sends every pass through ntt_pass_kernel (the round 1-4 path): same LDE words and same proof bytes as the
-    default build's direct passes, in a process of its own (the switch is read once)."""
+def test_ab_switches_keep_every_byte(gpu):
+    """The A/B switches of round 5, each in a process of its own (they are read once): P2GPU_NTT_DIRECT=0 sends every pass through
+    ntt_pass_kernel (the round 1-4 path), P2GPU_LEAF_LEVELS=0 leaves every tree level to merkle_level / merkle_tail instead of
+    building the first two inside the leaf-hash launch.  Same LDE words, same proof bytes (virtual-column wires tree, plain
+    Z / quotient trees, a 231-dense-column witness) as the default build."""
     import os
     import subprocess
     import sys
@@ -146,15 +148,19 @@ P = 0xFFFFFFFF00000001
 for d in (12, 15, 17, 19, 21):
     v = rng.integers(0, P, size=(2, 1 << d), dtype=np.uint64)
     print("LDE", d, hashlib.sha256(pkg.lde_batch(v, 3 if d <= 17 else 1).tobytes()).hexdigest())
-blob, wires = pkg.make_circuit(14, "ecdsa", 5)
-print("PROOF", hashlib.sha256(pkg.CircuitData(blob).prove(wires).to_bytes()).hexdigest())
+for d, mix in ((8, "sha"), (11, "sha"), (14, "ecdsa")):
+    blob, wires = pkg.make_circuit(d, mix, 5)
+    cd = pkg.CircuitData(blob)
+    print("PROOF", d, mix, hashlib.sha256(cd.prove(wires).to_bytes()).hexdigest())
+    cd.set("virtual_columns", 0)
+    print("PROOF-novirt", d, mix, hashlib.sha256(cd.prove(wires).to_bytes()).hexdigest())
 """.format(root=root)
     outs = []
-    for direct in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, P2GPU_NTT_DIRECT=direct), capture_output=True, text=True, timeout=900)
+    for env in ({}, {"P2GPU_NTT_DIRECT": "0"}, {"P2GPU_LEAF_LEVELS": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("LDE", "PROOF"))])
-    assert len(outs[0]) == 6 and outs[0] == outs[1]
+    assert len(outs[0]) == 11 and outs[0] == outs[1] == outs[2]
 
 
 @pytest.mark.parametrize("d", [21, 22])

@@ -712,13 +712,17 @@ def _assert_matches_gold(pkg, blob, wires, pis, g):
     cd.close()
 
 
-@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+@pytest.mark.parametrize("idx", range(6))
 def test_baseline_size_proofs_are_bit_exact(pkg, gpu, idx):
     """BASELINE.json configs[2] (2^20 LDE rows: `sha` = the bench workload, `ecdsa` = every gate kind,
-    `sha` + 4 public inputs = PoseidonGate rows) and configs[3] (2^22 LDE rows, every gate kind): the GPU
-    proof must equal the ORACLE's, stage by stage and as a whole.  The oracle ran in the build container
-    (tests/golden/gen_proof_digests.py --large; minutes of CPU); only SHA-256 digests travel."""
-    g = _gold("proof_digests_large.json")[idx]
+    `sha` + 4 public inputs = PoseidonGate rows), configs[3] (2^22 LDE rows, every gate kind) and -- round 5 -- configs[4]
+    (2^24 LDE rows: the `grammar` mix, and the bench workload's mix at that size): the GPU proof must equal the ORACLE's,
+    stage by stage and as a whole.  The oracle ran in the build container (tests/golden/gen_proof_digests.py --large /
+    --xlarge; minutes of CPU, the 2^24-row LDEs spilled to disk); only SHA-256 digests travel."""
+    gold = _gold("proof_digests_large.json")
+    if idx >= len(gold):
+        pytest.skip("no such entry in proof_digests_large.json")
+    g = gold[idx]
     out = pkg.make_circuit(g["degree_bits"], g["mix"], g["seed"], num_public_inputs=g["public_inputs"])
     blob, wires = out[0], out[1]
     pis = out[2] if g["public_inputs"] else ()

@@ -223,3 +223,24 @@ def test_stage_slicer_covers_the_proof(pkg, orc):
         assert st["pow_witness"] == int(tr.pow_witness).to_bytes(8, "little")
         assert len(st["public_inputs"]) == 8 * npi
         assert len(st["fri_commit_caps"]) == 400 * proof_stages.header(blob)["steps"]
+
+
+def test_block_commit_and_disk_spill_keep_the_proof(pkg, orc, tmp_path):
+    """The oracle's low-memory switches (round 5: the 2^24-row golden needs them on a 62 GB build box): ORC_COMMIT_BLOCK = columns per
+    block of the LDE's column-major staging buffer (oracle/poly.c batch_commit), ORC_SPILL_DIR / ORC_SPILL_MIN_GB = the batches'
+    row-major LDE as file mappings.  A process of its own with both forced on at a small size: the same proof bytes."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    blob, wires = pkg.make_circuit(7, "ecdsa", 3)
+    want, _ = orc.OracleCircuit(blob).prove(wires)
+    code = ("import sys,hashlib;sys.path.insert(0,%r);import __graft_entry__ as e;p=e.load_package();o=e.load_oracle();"
+            "b,w=p.make_circuit(7,'ecdsa',3);print('SHA',hashlib.sha256(o.OracleCircuit(b).prove(w)[0]).hexdigest())" % ROOT)
+    env = dict(os.environ, ORC_SPILL_DIR=str(tmp_path), ORC_SPILL_MIN_GB="0", ORC_COMMIT_BLOCK="8", ORC_TRACE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert "spilled to" in r.stderr                       # the file-mapping path really ran
+    assert ("SHA " + hashlib.sha256(want).hexdigest()) in r.stdout
+    assert not os.listdir(tmp_path)                       # unlinked as soon as they are mapped

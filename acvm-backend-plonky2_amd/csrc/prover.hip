@@ -2051,7 +2051,15 @@ static int prove_host(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, c
     if (c1 > c0)
       HIP_TRY(hipMemcpyAsync(c->wires_vals.p + (size_t)c0 * n, wires + (size_t)c0 * n, 8 * (size_t)(c1 - c0) * n, hipMemcpyHostToDevice,
                              c->stream));
-    if (int rc = shard_allgather(c, c->wires_vals.p + (size_t)q * cpr * n, c->wires_vals.p, 8 * (size_t)cpr * n)) return rc;
+    {
+      // (the exchange belongs to the proof's profile like the ones inside prove_impl: `profile` = 2 counts it)
+      EventProf xprof(c);
+      struct XGuard {
+        XGuard(Prof *p) { g_prof = p; }
+        ~XGuard() { g_prof = nullptr; }
+      } xguard(c->profile ? &xprof : nullptr);
+      if (int rc = shard_allgather(c, c->wires_vals.p + (size_t)q * cpr * n, c->wires_vals.p, 8 * (size_t)cpr * n)) return rc;
+    }
     return prove_impl(c, c->wires_vals.p, pis, n_pi, proof_out, proof_len, tm, now_ms() - t0);
   }
   const gl_t ninv = gl_inv((gl_t)n);

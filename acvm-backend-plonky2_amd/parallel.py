@@ -99,3 +99,55 @@ def max_over_ranks(seconds, group=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def exchange_plan(degree_bits, world_size, num_wires=234, num_constants_sigmas=84, num_challenges=2, partial_products=9,
+                  quotient_degree_factor=8, rate_bits=3, cap_height=4, num_queries=28, host_witness=False, dense_columns=None):
+    """The exchange steps of ONE coset-sharded proof (csrc/prover.hip shard_allgather call sites), in
+    order: [(what, bytes each rank sends)].  Every step is an all-gather over the `world_size` ranks, so a rank receives
+    (world_size - 1) x those bytes; nothing else crosses between the GPUs.  Host-side restatement for tests and budgets: the
+    GPU tests compare it with what the library counts (`profile` = 2: the exchange[...] pseudo-kernels of p2gpu_kernel_stats)."""
+    d, G, K = degree_bits, world_size, num_challenges
+    n, C = 1 << d, 1 << rate_bits
+    assert C % G == 0, "GPU q owns the cosets r = q (mod G): G divides 2^rate_bits"
+    cl = C // G                                    # cosets per rank
+    cap_bytes = cl * ((1 << cap_height) // C) * 32  # local subtree roots, 32 B per digest in device memory
+    nzp, nq = K * (1 + partial_products), K * quotient_degree_factor
+    nall = num_constants_sigmas + num_wires + nzp + nq
+    arity = []
+    db = d
+    while db > 5 and db + rate_bits - 4 >= cap_height:   # ConstantArityBits(4, 5) as build() derives it (hostcore.hip:290)
+        arity.append(4)
+        db -= 4
+    parts = 1
+    while parts < 16 and (n // (parts * 2)) >= 1024:
+        parts *= 2
+    plan = []
+    if host_witness and (dense_columns is None or dense_columns >= num_wires):
+        # p2gpu_prove (the whole matrix in host RAM): every rank pulls W / G columns over its own PCIe link and the blocks are
+        # exchanged.  Through p2gpu_prove_sparse (dense_columns < W: the caller says which wires are unused) every rank uploads
+        # the dense columns itself and nothing is exchanged
+        plan.append(("witness column blocks", 8 * -(-num_wires // G) * n))
+    plan.append(("wires cap", cap_bytes))
+    plan.append(("Z / partial products cap", cap_bytes))
+    plan.append(("quotient interpolants", K * cl * n * 8))
+    plan.append(("quotient cap", cap_bytes))
+    plan.append(("opening partial sums", -(-(nall + K) // G) * parts * 2 * 8))
+    plan.append(("first FRI tree cap", cap_bytes))      # later FRI trees are small and built whole on every rank
+    plan.append(("PoW minima", 8))                      # one per grinding batch; the first batch almost always holds a witness
+    per_query = 0
+    for cols in (num_constants_sigmas, num_wires, nzp, nq):
+        per_query += cols + 4 * (d - 1)                  # the row + its Merkle path (leaves n per coset -> 2 per coset)
+    dcur = d
+    for ab in arity:
+        per_query += 2 * (1 << ab) + 4 * (dcur - ab - 1)
+        dcur -= ab
+    plan.append(("query rows and paths", 8 * num_queries * per_query))
+    return plan
+
+
+def exchange_budget(plan, world_size, link_gbps=153.0, latency_us=60.0):
+    """Seconds of one sharded proof spent in its exchanges under a simple model: every rank drives all its world_size - 1 xGMI
+    links at once (direct peer copies / grouped send-recv, not a ring), `latency_us` per exchange (measured between two ranks on one
+    GPU: 60 us below 1 MB, profiles/NUMBERS.md), `link_gbps` per link and direction."""
+    return sum(latency_us * 1e-6 + b / (link_gbps * 1e9) for _, b in plan)

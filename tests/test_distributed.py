@@ -137,3 +137,37 @@ def test_bench_refuses_more_gpus_than_the_box_has():
     # a rank whose torchrun world disagrees with --gpus refuses as well (the line's n_gpus must be the N asked for)
     r2 = _bench("--gpus", "4", "--dry", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
     assert r2.returncode == 2 and "WORLD_SIZE=2" in r2.stderr
+
+
+@pytest.mark.parametrize("d", [17, 19, 21])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_exchange_plan_of_a_sharded_proof(pkg, d, world):
+    """DESIGN.md section 7's table, walked without a GPU: the exchanges of one coset-sharded proof, their
+    number and their bytes, for the BASELINE sizes on 2 / 4 / 8 GPUs.  `exchange_plan` restates the shard_allgather call sites of
+    csrc/prover.hip; the GPU suite checks it against what the library counts (test_exchange_plan_matches_the_library)."""
+    n, G = 1 << d, world
+    plan = pkg.parallel.exchange_plan(d, world)
+    names = [p[0] for p in plan]
+    assert names == ["wires cap", "Z / partial products cap", "quotient interpolants", "quotient cap", "opening partial sums",
+                     "first FRI tree cap", "PoW minima", "query rows and paths"]
+    by = dict(plan)
+    # the north_star's "all-gather to reassemble Merkle caps": 16 entries x 32 B over all ranks, four commitments
+    assert by["wires cap"] * G == 16 * 32 and sum(1 for p in plan if p[0].endswith("cap")) == 4
+    # the quotient's per-coset interpolants: 2 challenges x N x 8 B over all ranks (16.8 MB at d = 17)
+    assert by["quotient interpolants"] * G == 2 * 8 * n * 8
+    # 354 + 2 opened polynomials, 16 partial sums of 16 B each at these sizes, split over the ranks: 91 KB in total
+    assert by["opening partial sums"] == -(-356 // G) * 16 * 16
+    assert by["PoW minima"] == 8
+    steps = len([1 for db in range(d, 5, -4)])
+    per_query = (84 + 234 + 20 + 16) + 4 * 4 * (d - 1) + sum(32 + 4 * (d - 4 * (s + 1) - 1) for s in range(steps))
+    assert by["query rows and paths"] == 8 * 28 * per_query
+    # everything but the interpolants is latency: < 0.5 MB per rank and proof
+    assert sum(b for nm, b in plan if nm != "quotient interpolants") < 512 * 1024
+    # the host-witness entry point adds exactly one exchange: W / G columns per rank
+    hw = pkg.parallel.exchange_plan(d, world, host_witness=True)
+    assert len(hw) == len(plan) + 1 and hw[0] == ("witness column blocks", 8 * -(-234 // G) * n) and hw[1:] == plan
+    # ... the compact entry point (p2gpu_prove_sparse): every rank uploads the dense columns itself, nothing is exchanged
+    assert pkg.parallel.exchange_plan(d, world, host_witness=True, dense_columns=80) == plan
+    # budget: eight exchanges at ~60 us each + the interpolants over G - 1 links at once
+    t = pkg.parallel.exchange_budget(plan, world)
+    assert 8 * 60e-6 < t < 8 * 60e-6 + 2 * 8 * n * 8 / G / 153e9 + 1e-4

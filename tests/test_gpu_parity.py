@@ -880,6 +880,52 @@ def test_poseidon_hasher_full_size_and_sharded_exercise(pkg, orc, gpu):
 
 # ---- one process, several devices: the device group behind p2gpu_init(ids, n > 1) ----------------------------------------
 @pytest.mark.parametrize("world", [2, 4, 8])
+def test_exchange_plan_matches_the_library(pkg, gpu, world):
+    """parallel.exchange_plan (the host-side restatement DESIGN.md section 7's table and the CPU test are built on) against what
+    the library itself counts for a sharded proof: `profile` = 2 brackets every shard_allgather with events and files it under
+    its payload class -- number of exchanges and bytes over all ranks must agree, resident and host witness."""
+    import torch
+
+    def classes(plan):
+        out = {"small": [0, 0], "mid": [0, 0], "big": [0, 0]}
+        for _, b in plan:
+            k = "small" if b <= 4096 else ("mid" if b < (1 << 20) else "big")
+            out[k][0] += 1
+            out[k][1] += b * world
+        return out
+
+    try:
+        pkg.init([0] * world)
+        d = 15
+        blob, wires = pkg.make_circuit(d, "sha", 9)
+        hdr = blob[:256].view(np.uint32)
+        cd = pkg.CircuitData(blob)
+        wd = torch.from_numpy(wires.view(np.int64)).cuda()
+        for host, w, ncols in ((False, wd, None), (True, wires, None)):
+            plan = pkg.parallel.exchange_plan(d, world, num_wires=int(hdr[3]), num_constants_sigmas=int(hdr[5]) + int(hdr[4]), host_witness=host,
+                                              dense_columns=ncols)
+            want = classes(plan)
+            cd.prove(w)
+            cd.set("profile", 2)
+            cd.prove(w)
+            st = cd.kernel_stats()
+            cd.set("profile", 0)
+            got = {"small": [0, 0], "mid": [0, 0], "big": [0, 0]}
+            for k, v in st.items():
+                if k.startswith("exchange["):
+                    key = "small" if "<=4KB" in k else ("mid" if "<1MB" in k else "big")
+                    got[key] = [v["launches"], int(v["bytes"])]
+            extra_pow = got["small"][0] - want["small"][0]      # a second grinding batch adds one 8-byte exchange (rare)
+            assert 0 <= extra_pow <= 2, (got, want)
+            want["small"][0] += extra_pow
+            want["small"][1] += 8 * world * extra_pow
+            assert got == want, (host, ncols, got, want)
+        cd.close()
+    finally:
+        pkg.init([0])
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_single_process_device_group(pkg, orc, gpu, world):
     """p2gpu_init with several ids makes every circuit handle a device group: ONE caller thread, one proof coset-sharded
     over the ranks, exchanges as peer copies between the ranks' streams (no RCCL, no second process) -- what a single

@@ -251,6 +251,8 @@ struct CircuitState {
   DBuf<uint64_t> gather_ptrs;
   DBuf<gl_t> gather_out;
   size_t gather_cap = 0;
+  std::vector<uint64_t> h_ptrs;  // host scratch that keeps its capacity from proof to proof: the gather's pointer list,
+  std::vector<uint8_t> h_out;    // the proof bytes when the caller's buffer is smaller than p2gpu_proof_size_bound
   // coset sharding across ranks (one process per GPU); world = 1: everything local
   int shard_rank = 0, shard_world = 1;
   p2gpu_allgather_fn shard_fn = nullptr;  // host callback transport (tests over gloo)

@@ -528,11 +528,16 @@ int batch_alloc(p2gpu_circuit *c, Batch &b, uint32_t cols) {
   return tree_alloc(b, c->C, c->n, cap_per);
 }
 
+// proof bytes, written through a cursor into storage that outlives the proof (the caller's buffer when it is large enough,
+// else the handle's): a fresh 200 KB vector per proof is an mmap, its page faults and an munmap -- 20 of the serialiser's 45 us
 struct Buf {
-  std::vector<uint8_t> v;
+  uint8_t *base = nullptr;
+  size_t len = 0, cap = 0;
+  bool overflow = false;
   void put(const void *p, size_t n) {
-    const uint8_t *q = (const uint8_t *)p;
-    v.insert(v.end(), q, q + n);
+    if (len + n > cap) { overflow = true; return; }
+    memcpy(base + len, p, n);
+    len += n;
   }
   void u64(uint64_t x) { put(&x, 8); }
   void ext(ext_t e) {
@@ -935,7 +940,8 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
 
   // ---- query gather: one launch, one D2H ----
   const unsigned lgC = c->rate_bits;
-  std::vector<uint64_t> ptrs;
+  std::vector<uint64_t> &ptrs = c->h_ptrs;  // (the handle's: its capacity survives the proof -- one prove per handle at a time)
+  ptrs.clear();
   ptrs.reserve(c->gather_cap);
   auto push_dig = [&](const Batch &b, size_t pos) {
     const uint64_t base = (uint64_t)(uintptr_t)(b.dig.p + pos);
@@ -1039,7 +1045,16 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
 
   // ---- serialise: plonky2 ProofWithPublicInputs::to_bytes ----
   Buf out;
-  out.v.reserve(p2gpu_proof_size_bound(c));
+  {
+    const size_t bound = p2gpu_proof_size_bound(c);
+    if (*proof_len >= bound) {
+      out.base = proof_out;
+    } else {
+      if (c->h_out.size() < bound) c->h_out.resize(bound);
+      out.base = c->h_out.data();
+    }
+    out.cap = bound;
+  }
   for (auto &dg : c->wires.cap) out.dig(dg);
   for (auto &dg : c->zp.cap) out.dig(dg);
   for (auto &dg : c->quot.cap) out.dig(dg);
@@ -1085,13 +1100,17 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
   // the proof itself; bound the backlog
   if (c->profile && c->pending.size() > 16384) flush_kstats(c);
   if (tm) *tm = T;
-  if (out.v.size() > *proof_len) {
-    *proof_len = out.v.size();
-    set_err("proof buffer too small: need %zu bytes", out.v.size());
+  if (out.overflow) {
+    set_err("internal: proof longer than p2gpu_proof_size_bound");
+    return P2GPU_E_DEVICE;
+  }
+  if (out.len > *proof_len) {
+    *proof_len = out.len;
+    set_err("proof buffer too small: need %zu bytes", out.len);
     return P2GPU_E_BUFFER;
   }
-  memcpy(proof_out, out.v.data(), out.v.size());
-  *proof_len = out.v.size();
+  if (out.base != proof_out) memcpy(proof_out, out.base, out.len);
+  *proof_len = out.len;
   g_hp.mark("serialise");
   g_hp.dump();
   return P2GPU_OK;

@@ -39,7 +39,7 @@ def main():
             if m:
                 cur = m.group(1)
                 body[cur] = []
-            elif l.startswith("s_endpgm"):
+            elif l.startswith(".Lfunc_end"):   # (not the first s_endpgm: a kernel with an early exit has several)
                 cur = None
             elif cur and l and not l.startswith((";", ".", "/")) and not l.endswith(":"):
                 body[cur].append(l)

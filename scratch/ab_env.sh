@@ -1,10 +1,18 @@
 #!/bin/bash
-# A/B of an environment knob on one box, alternating: scratch/ab_env.sh NAME v1 v2 ...   (bench flags in P2GPU_BENCH_FLAGS)
-name=$1; shift
-for rep in 1 2; do
-for v in "$@"; do
-  env $name=$v python bench.py --steps 48 --warmup 8 --no-cpu-baseline --pipelined 0 --profile-steps 3 $P2GPU_BENCH_FLAGS 2>/dev/null | python -c "
-import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); k=d['kernel_ms_per_proof']
-print('$name=$v', round(d['value'],1), 'proofs/s;', round(d['latency_ms_single_proof'],3), 'ms lone;', {n: v for n, v in k.items() if 'hash_lde_leaves_kf_kernel<true>' in n or 'ntt_pass_kernel<1, false, 12>' in n or 'quotient_kernel' in n}, 'sum', round(sum(k.values()),3))"
-done
-done
+# A/B of environment switches on the bench workload: for each "NAME=VALUE" argument (and the default) print value, lone latency and
+# the top lone kernel times.   bash scratch/ab_env.sh [--args "bench args"] VAR=val [VAR=val ...]
+ARGS=""
+if [ "$1" == "--args" ]; then ARGS="$2"; shift 2; fi
+run() {
+  env $1 python bench.py --no-cpu-baseline --no-cold-process --pipelined 0 --detail /tmp/ab_detail.json $ARGS > /dev/null 2>&1
+  python - "$1" <<'PY'
+import json, sys
+d = json.load(open("/tmp/ab_detail.json"))
+ks = d["kernel_ms_per_proof_lone"]
+lde = sum(v for k, v in ks.items() if k.startswith(("ntt_dit", "ntt_pass_kernel<1")))
+print(f"{sys.argv[1]:28s} value {d['value']:7.1f}  lone {d['latency_ms_single_proof']:6.3f} ms  host {d['value_host_witness']:6.1f}  LDE {lde:.3f}  " +
+      "  ".join(f"{k.split('(')[0][:34]} {v:.3f}" for k, v in list(ks.items())[:6]))
+PY
+}
+run "P2GPU_NOP=1"
+for kv in "$@"; do run "$kv"; done

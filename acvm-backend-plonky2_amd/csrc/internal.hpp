@@ -36,6 +36,7 @@ struct NttPass {
   // ftw_off: offset in the plan's table of the folded twiddles of the round before the last (see fold_table_kernel)
   bool direct = false;
   uint32_t ftw_off = 0;
+  uint32_t ftw2_off = 0;  // head pass: the folded table in ntt_dit_head2_kernel's lane order
 };
 struct NttPlan {
   uint32_t d = 0;

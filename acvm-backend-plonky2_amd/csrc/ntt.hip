@@ -177,6 +177,7 @@ struct PassArgs {
   const uint32_t *colnz;        // optional [cols]: class of every column (ColHints, internal.hpp); only class 2 (dense)
                                 // columns are transformed here, the others are written by structured_fill_kernel
   const gl_t *ftw;              // direct DIT passes: folded twiddles of the round before the last (fold_table_kernel)
+  const gl_t *ftw2;             // ntt_dit_head2_kernel: the same values in its lane order (head_fold_table_kernel)
 };
 
 __device__ __forceinline__ uint32_t gidx(uint32_t e, uint32_t hi_base, uint32_t lo0, uint32_t s, uint32_t tb) {
@@ -486,19 +487,26 @@ __device__ __forceinline__ void round_folded(gl_t *lds, const PassArgs &A, uint3
 }
 // The last round of a pass, LDS -> registers -> global: RL layers on the tile's top bits, shift twiddles (the round before had RP
 // layers; its folded table carried the rest), then the pass's output scale.
-template <bool INV, int RL, int RP>
+// second swizzle, for the head pass whose first round runs in registers (ntt_dit_head2_kernel): its LDS accesses differ, within a
+// lane group, in element bits {3,4,5,6} (16-lane store groups after round 0), {6..10} / {6..9} (round on bits 3-5, wave = bits 0-2),
+// {3,4,5,9,10} / {3,4,5,9} (round on bits 6-8) and {0..4} (last round): slot bits s0 = e0^e3^e6, s1 = e1^e4^e7, s2 = e2^e5^e8,
+// s3 = e3^e9, s4 = e4^e10 have full rank on each of them (found by exhaustive search over shift-and-mask forms: the only two-term
+// one).  GF(2)-linear like pidx: pidx2(a ^ b) = pidx2(a) ^ pidx2(b).
+__device__ __forceinline__ constexpr uint32_t pidx2(uint32_t e) { return e ^ ((e >> 3) & 7u) ^ ((e >> 6) & 31u); }
+template <bool INV, int RL, int RP, int SW = 0>
 __device__ __forceinline__ void round_to_global(const gl_t *lds, gl_t *dst, const PassArgs &A, uint32_t hi_base, uint32_t lo0) {
   constexpr int R = 1 << RL;
   constexpr uint32_t beta0 = 12 - RL;
+  auto sw = [](uint32_t e) { return SW ? pidx2(e) : pidx(e); };
   uint32_t lj[R];
 #pragma unroll
-  for (int j = 0; j < R; j++) lj[j] = pidx((uint32_t)j << beta0);
+  for (int j = 0; j < R; j++) lj[j] = sw((uint32_t)j << beta0);
   const bool post = A.post != 1;
 #pragma unroll
   for (uint32_t it = 0; it < ((1u << beta0) / NTT_THREADS); it++) {
     const uint32_t g = threadIdx.x + it * NTT_THREADS;
     gl_t v[R];
-    const uint32_t l0 = pidx(g);
+    const uint32_t l0 = sw(g);
 #pragma unroll
     for (int j = 0; j < R; j++) v[j] = lds[l0 ^ lj[j]];
     shift_twiddles_k<INV, RL, RP>(v, (g >> (beta0 - RP)) & ((1u << RP) - 1));
@@ -561,6 +569,84 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_WAVES) void ntt_dit_head_kerne
   round_folded<INV, 3>(lds, A, 6, 3, 0, A.ftw);
   __syncthreads();
   round_to_global<INV, 3, 3>(lds, dst, A, tbase, 0);
+}
+// The same pass with its FIRST round in registers too, and the second one on shifts (w_64 = 2^3, so the 64-point
+// transform on tile bits 0-5 needs no table): a lane loads 8 CONSECUTIVE words (64 B: the round on bits 0-2 is then its own eight
+// registers; a wave still covers 4 KB contiguous), scales them, runs the twiddle-free 8-point transform and only then stores to LDS.
+// The round on bits 3-5 multiplies input j by w_64^(k1 brev(j)), k1 = element bits 0-2: made WAVE-uniform by giving wave w the
+// groups with k1 = w (lane = bits 6-11), so the eight shift amounts are compile-time behind one scalar branch; the round on bits
+// 6-8 (folded table, laid out in this kernel's lane order: head_fold_table_kernel) keeps wave <-> k1 and therefore needs no barrier
+// in between; then the last round -> global as in ntt_dit_head_kernel.  Against that kernel: 3 instead of 4 LDS round trips, 7 of 8
+// general products per element gone, the same two barriers.  LDS addresses through pidx2 (every access conflict-free).
+template <bool INV>
+__global__ __launch_bounds__(NTT_THREADS, NTT_MIN_WAVES) void ntt_dit_head2_kernel(PassArgs A) {
+  extern __shared__ gl_t lds[];
+  uint32_t tile, col, coset;
+  if (!pass_unit(A, tile, col, coset)) return;
+  const size_t n = (size_t)1 << A.d;
+  const gl_t *src = A.src + ((size_t)(A.src_single ? 0 : coset) * A.cols + col) * n;
+  gl_t *dst = A.dst + ((size_t)coset * A.cols + col) * n;
+  const gl_t *scale = A.scale ? A.scale + (size_t)(A.coset_first + coset * A.coset_stride) * n : nullptr;
+  const uint32_t tbase = tile << 12, t = threadIdx.x, w = t >> 6, l = t & 63u;
+  gl_t v[8];
+  {
+    const ulonglong2 *s2 = reinterpret_cast<const ulonglong2 *>(src + tbase + 8 * t);  // (columns and tiles are 64 B aligned)
+    ulonglong2 x2[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) x2[i] = s2[i];
+    if (scale) {
+      const ulonglong2 *c2 = reinterpret_cast<const ulonglong2 *>(scale + tbase + 8 * t);
+      ulonglong2 sc[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) sc[i] = c2[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        v[2 * i] = gl_mul(x2[i].x, sc[i].x);
+        v[2 * i + 1] = gl_mul(x2[i].y, sc[i].y);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        v[2 * i] = x2[i].x;
+        v[2 * i + 1] = x2[i].y;
+      }
+    }
+  }
+  dft_regs<3, 1, INV>(v);  // bits 0-2: no twiddles
+  {
+    const uint32_t p0 = pidx2(8 * t);  // pidx2(k) = k for k < 8
+#pragma unroll
+    for (int k = 0; k < 8; k++) lds[p0 ^ (uint32_t)k] = v[k];
+  }
+  __syncthreads();
+  {  // bits 3-5: element = w + 8 j + 64 l
+    const uint32_t p0 = pidx2(w | (l << 6));
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = lds[p0 ^ pidx2((uint32_t)j << 3)];
+    shift_twiddles_k<INV, 3, 3>(v, w);
+    dft_regs<3, 1, INV>(v);
+#pragma unroll
+    for (int j = 0; j < 8; j++) lds[p0 ^ pidx2((uint32_t)j << 3)] = v[j];
+  }
+  asm volatile("" ::: "memory");  // the same wave, the same 512 elements (bits 0-2 = w): in-order LDS operations, no barrier
+  {  // bits 6-8: element = w + 8 a + 64 i + 512 J, lane = a + 8 J; twiddles F2[e * 512 + t]
+    const uint32_t p0 = pidx2(w | ((l & 7u) << 3) | ((l >> 3) << 9));
+    gl_t tw[8];
+    const gl_t *tp = A.ftw2 + t;
+#pragma unroll
+    for (int e = 0; e < 8; e++) tw[e] = tp[e * NTT_THREADS];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = lds[p0 ^ pidx2((uint32_t)i << 6)];
+    static_for<0, 8>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      v[i] = gl_mul(v[i], tw[brev_c(i, 3)]);
+    });
+    dft_regs<3, 1, INV>(v);
+#pragma unroll
+    for (int i = 0; i < 8; i++) lds[p0 ^ pidx2((uint32_t)i << 6)] = v[i];
+  }
+  __syncthreads();
+  round_to_global<INV, 3, 3, 1>(lds, dst, A, tbase, 0);
 }
 // A strided DIT pass of a = 3 + RM + RL layers (RM = 0: no middle round; RL = 0: a = 3, no LDS at all) on 2^12-element tiles of
 // 2^a rows x 2^tb contiguous words: first round global -> registers (its 8 elements are the rows base + j: one coalesced
@@ -655,6 +741,20 @@ __global__ void fold_table_kernel(gl_t *out, gl_t root_n, uint32_t d, uint32_t s
   const uint64_t ex = (((uint64_t)lo * e) << (d - s0 - r)) + (((uint64_t)lo * bitrev32(J, rl)) << (d - s0 - r - rl));
   out[i] = gl_pow(root_n, ex);
 }
+// the head pass's folded table (s0 = 6, r = 3, rl = 3) in the lane order of ntt_dit_head2_kernel: F2[e * 512 + t] for lane t whose
+// group is lo = (t >> 6) + 8 (t & 7), J = (t & 63) >> 3
+__global__ void head_fold_table_kernel(gl_t *out, gl_t root_n, uint32_t d) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 8u * 512u) return;
+  const uint32_t e = i >> 9, t = i & 511u, lo = (t >> 6) + 8u * (t & 7u), J = (t & 63u) >> 3;
+  const uint64_t ex = (((uint64_t)lo * e) << (d - 9)) + (((uint64_t)lo * bitrev32(J, 3)) << (d - 12));
+  out[i] = gl_pow(root_n, ex);
+}
+// P2GPU_NTT_HEAD=1: the head pass through ntt_dit_head_kernel (first two rounds in LDS with table twiddles) instead of ntt_dit_head2_kernel
+static bool head2_on() {
+  static const bool on = [] { const char *e = getenv("P2GPU_NTT_HEAD"); return !(e && *e == '1'); }();
+  return on;
+}
 // P2GPU_NTT_DIRECT=0: every pass through ntt_pass_kernel (A/B measurements, and the reference the direct kernels are tested against)
 static bool direct_on() {
   static const bool on = [] { const char *e = getenv("P2GPU_NTT_DIRECT"); return !(e && *e == '0'); }();
@@ -734,6 +834,10 @@ NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse) {
         for (uint32_t i = 0; i < q; i++) bq += np.r[i];
         np.ftw_off = (uint32_t)total;
         total += (size_t)1 << (np.r[q] + rl + (bq - ps.tb + ps.s));
+        if (ps.s == 0) {  // the head pass: the same 4096 values once more, in ntt_dit_head2_kernel's lane order
+          np.ftw2_off = (uint32_t)total;
+          total += 4096;
+        }
       }
     }
     p->passes.push_back(np);
@@ -763,6 +867,7 @@ NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse) {
         for (uint32_t i = 0; i < q; i++) bq += np.r[i];
         const uint32_t s0 = bq - np.tb + np.s, cnt = 1u << (np.r[q] + rl + s0);
         hipLaunchKernelGGL(fold_table_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, p->ptw + np.ftw_off, root, d, s0, np.r[q], rl);
+        if (np.s == 0) hipLaunchKernelGGL(head_fold_table_kernel, dim3(16), dim3(256), 0, st, p->ptw + np.ftw2_off, root, d);
       }
     }
   }
@@ -867,6 +972,7 @@ static void fill_pass_args(PassArgs &A, const NttPlan *plan, size_t i, const gl_
   A.nrounds = ps.nrounds;
   A.colnz = colnz;
   A.ftw = ps.direct ? plan->ptw + ps.ftw_off : nullptr;
+  A.ftw2 = ps.direct && ps.s == 0 ? plan->ptw + ps.ftw2_off : nullptr;
   for (int k = 0; k < MAX_ROUNDS; k++) { A.r[k] = ps.r[k]; A.tw_off[k] = ps.tw_off[k]; }
   A.tiles = 1u << (plan->d - (A.a + A.tb));
   A.cols_grid = cols; A.cosets = cosets;
@@ -901,7 +1007,10 @@ static void ntt_passes(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_
       const NttPass &ps = plan->passes[i];
       const uint32_t rm = ps.nrounds == 3 ? ps.r[1] : 0, rl = ps.nrounds >= 2 ? ps.r[ps.nrounds - 1] : 0;
       // (profile names = rocprofv3's demangled symbols)
-      if (ps.s == 0) {
+      if (ps.s == 0 && head2_on()) {
+        ProfScope psd("ntt_dit_head2_kernel<false>", bytes);
+        hipLaunchKernelGGL((ntt_dit_head2_kernel<false>), grid, dim3(NTT_THREADS), lb, st, A);
+      } else if (ps.s == 0) {
         ProfScope psd("ntt_dit_head_kernel<false>", bytes);
         hipLaunchKernelGGL((ntt_dit_head_kernel<false>), grid, dim3(NTT_THREADS), lb, st, A);
       } else {

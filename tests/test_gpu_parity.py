@@ -130,7 +130,8 @@ def test_direct_dit_passes_match_oracle(pkg, orc, gpu, d):
 
 def test_ab_switches_keep_every_byte(gpu):
     """The A/B switches of round 5, each in a process of its own (they are read once): P2GPU_NTT_DIRECT=0 sends every pass through
-    ntt_pass_kernel (the round 1-4 path), P2GPU_LEAF_LEVELS=0 leaves every tree level to merkle_level / merkle_tail instead of
+    ntt_pass_kernel (the round 1-4 path), P2GPU_NTT_HEAD=1 takes the head pass with its first two rounds in LDS (ntt_dit_head_kernel),
+    P2GPU_LEAF_LEVELS=0 leaves every tree level to merkle_level / merkle_tail instead of
     building the first two inside the leaf-hash launch.  Same LDE words, same proof bytes (virtual-column wires tree, plain
     Z / quotient trees, a 231-dense-column witness) as the default build."""
     import os
@@ -156,11 +157,11 @@ for d, mix in ((8, "sha"), (11, "sha"), (14, "ecdsa")):
     print("PROOF-novirt", d, mix, hashlib.sha256(cd.prove(wires).to_bytes()).hexdigest())
 """.format(root=root)
     outs = []
-    for env in ({}, {"P2GPU_NTT_DIRECT": "0"}, {"P2GPU_LEAF_LEVELS": "0"}):
+    for env in ({}, {"P2GPU_NTT_DIRECT": "0"}, {"P2GPU_LEAF_LEVELS": "0"}, {"P2GPU_NTT_HEAD": "1"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("LDE", "PROOF"))])
-    assert len(outs[0]) == 11 and outs[0] == outs[1] == outs[2]
+    assert len(outs[0]) == 11 and outs[0] == outs[1] == outs[2] == outs[3]
 
 
 @pytest.mark.parametrize("d", [21, 22])

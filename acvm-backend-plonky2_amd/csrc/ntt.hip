@@ -719,6 +719,188 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_MIN_WAVES) void ntt_dit_strided_ke
   }
 }
 
+// ---- the mirror images for the inverse (DIF) transforms: values -> coefficients -------------------------------------------------
+// A DIF round multiplies its OUTPUTS: after the round on [beta, beta + r) output j takes w^-(lo brev(j)), lo = the element's bits
+// below beta.  For the pass's FIRST (top) round lo = lo' + 2^s0' k with k the INPUT index of the round below: w^-(2^s0' k brev(j)) is a
+// power of w_64 -- a shift, k wave-uniform -- applied at once, and w^-(lo' brev(j)) is constant over the group of the round below
+// (fixed lo', j = its `high`), so that round's output twiddles carry it (the same folded table, inverse root).  First round from
+// global memory, last round to it.
+template <bool INV, int RL, int RP, int SW = 0>
+__device__ __forceinline__ void round_from_global(const gl_t *src, gl_t *lds, const PassArgs &A, uint32_t hi_base, uint32_t lo0) {
+  constexpr int R = 1 << RL;
+  constexpr uint32_t beta0 = 12 - RL;
+  auto sw = [](uint32_t e) { return SW ? pidx2(e) : pidx(e); };
+#pragma unroll
+  for (uint32_t it = 0; it < ((1u << beta0) / NTT_THREADS); it++) {
+    const uint32_t g = threadIdx.x + it * NTT_THREADS;
+    const uint32_t a0 = hi_base + ((g >> A.tb) << A.s) + lo0 + (g & ((1u << A.tb) - 1));
+    gl_t v[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) v[j] = src[a0 + ((uint32_t)j << (beta0 - A.tb + A.s))];
+    dft_regs<RL, 0, INV>(v);
+    shift_twiddles_k<INV, RL, RP>(v, (g >> (beta0 - RP)) & ((1u << RP) - 1));
+    const uint32_t l0 = sw(g);
+#pragma unroll
+    for (int j = 0; j < R; j++) lds[l0 ^ sw((uint32_t)j << beta0)] = v[j];
+  }
+}
+// DIF round in LDS whose OUTPUT twiddles are the folded table (its own general twiddle x the top round's deferred part)
+template <bool INV, int LOGR>
+__device__ __forceinline__ void round_folded_dif(gl_t *lds, const PassArgs &A, uint32_t beta0, uint32_t rl, uint32_t lo0, const gl_t *ftw) {
+  constexpr int R = 1 << LOGR;
+  const uint32_t ngroups = 1u << (12 - LOGR);
+  const uint32_t s0 = beta0 - A.tb + A.s;
+  uint32_t lj[R];
+#pragma unroll
+  for (int j = 0; j < R; j++) lj[j] = pidx((uint32_t)j << beta0);
+  const size_t estride = (size_t)1 << (s0 + rl);
+  for (uint32_t g = threadIdx.x; g < ngroups; g += NTT_THREADS) {
+    const uint32_t low = g & ((1u << beta0) - 1), high = g >> beta0;
+    const uint32_t base = (high << (beta0 + LOGR)) | low;
+    const uint32_t lo = ((low >> A.tb) << A.s) + lo0 + (low & ((1u << A.tb) - 1));
+    gl_t v[R], t[R];
+    uint32_t li[R];
+    const uint32_t l0 = pidx(base);
+#pragma unroll
+    for (int j = 0; j < R; j++) li[j] = l0 ^ lj[j];
+#pragma unroll
+    for (int j = 0; j < R; j++) v[j] = lds[li[j]];
+    const gl_t *tp = ftw + ((size_t)high << s0) + lo;
+#pragma unroll
+    for (int e = 0; e < R; e++) {
+      t[e] = *tp;
+      tp += estride;
+    }
+    dft_regs<LOGR, 0, INV>(v);
+    static_for<0, R>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      v[j] = gl_mul(v[j], t[brev_c(j, LOGR)]);
+    });
+#pragma unroll
+    for (int j = 0; j < R; j++) lds[li[j]] = v[j];
+  }
+}
+// A strided DIF pass of a = 3 + RM + RL layers: top round (RL layers) global -> registers -> LDS with shift twiddles, [middle round
+// in LDS with the folded table,] bottom round (3 layers) LDS -> registers -> global.  RL = 0: a = 3, one round, no LDS.
+template <bool INV, int RM, int RL>
+__global__ __launch_bounds__(NTT_THREADS, NTT_MIN_WAVES) void ntt_dif_strided_kernel(PassArgs A) {
+  extern __shared__ gl_t lds[];
+  uint32_t tile, col, coset;
+  if (!pass_unit(A, tile, col, coset)) return;
+  const size_t n = (size_t)1 << A.d;
+  const gl_t *src = A.src + ((size_t)(A.src_single ? 0 : coset) * A.cols + col) * n;
+  gl_t *dst = A.dst + ((size_t)coset * A.cols + col) * n;
+  const uint32_t runs = 1u << (A.s - A.tb);
+  const uint32_t hi = tile / runs, lo0 = (tile % runs) << A.tb;
+  const uint32_t hi_base = hi << (A.s + A.a);
+  if constexpr (RL != 0) {
+    round_from_global<INV, RL, (RM != 0 ? RM : 3)>(src, lds, A, hi_base, lo0);
+    __syncthreads();
+    if constexpr (RM != 0) {
+      round_folded_dif<INV, RM>(lds, A, A.tb + 3, RL, lo0, A.ftw);
+      __syncthreads();
+    }
+  }
+  {
+    // bottom round: group g = lane; low = its tb contiguous bits, high = the tile bits above the round
+    const uint32_t g = threadIdx.x, low = g & ((1u << A.tb) - 1), high = g >> A.tb;
+    const uint32_t base = (high << (A.tb + 3)) | low;
+    const uint32_t a0 = hi_base + ((high << 3) << A.s) + lo0 + low, lo = lo0 + low;
+    gl_t v[8], t[8];
+    if constexpr (RL == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = src[a0 + ((uint32_t)j << A.s)];
+    } else {
+      const uint32_t l0 = pidx(base);
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = lds[l0 ^ pidx((uint32_t)j << A.tb)];
+    }
+    constexpr bool FOLD1 = RM == 0 && RL != 0;  // the bottom round is the one below the top
+    if constexpr (FOLD1) {
+      const gl_t *tp = A.ftw + ((size_t)high << A.s) + lo;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        t[e] = *tp;
+        tp += (size_t)1 << (A.s + RL);
+      }
+    } else {
+      const gl_t *tp = A.ptw + A.tw_off[0] + lo;
+#pragma unroll
+      for (int e = 1; e < 8; e++) {
+        t[e] = *tp;
+        tp += (size_t)1 << A.s;
+      }
+    }
+    dft_regs<3, 0, INV>(v);
+    static_for<(FOLD1 ? 0 : 1), 8>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      v[j] = gl_mul(v[j], t[brev_c(j, 3)]);
+    });
+    if (A.post != 1) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = gl_mul(v[j], A.post);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) dst[a0 + ((uint32_t)j << A.s)] = v[j];
+  }
+}
+// The 12-layer LAST pass of a DIF transform (contiguous tiles), the mirror of ntt_dit_head2_kernel: round on bits 9-11 from a
+// coalesced load with shift twiddles -> LDS | rounds on bits 6-8 (folded table) and 3-5 (shifts) with wave = element bits 0-2, no
+// barrier between them | round on bits 0-2 in registers, output scale, 64 B per lane to global.
+template <bool INV>
+__global__ __launch_bounds__(NTT_THREADS, NTT_MIN_WAVES) void ntt_dif_tail2_kernel(PassArgs A) {
+  extern __shared__ gl_t lds[];
+  uint32_t tile, col, coset;
+  if (!pass_unit(A, tile, col, coset)) return;
+  const size_t n = (size_t)1 << A.d;
+  const gl_t *src = A.src + ((size_t)(A.src_single ? 0 : coset) * A.cols + col) * n;
+  gl_t *dst = A.dst + ((size_t)coset * A.cols + col) * n;
+  const uint32_t tbase = tile << 12, t = threadIdx.x, w = t >> 6, l = t & 63u;
+  round_from_global<INV, 3, 3, 1>(src, lds, A, tbase, 0);
+  __syncthreads();
+  gl_t v[8];
+  {  // bits 6-8: element = w + 8 a + 64 i + 512 J, lane = a + 8 J; output twiddles F2[e * 512 + t]
+    const uint32_t p0 = pidx2(w | ((l & 7u) << 3) | ((l >> 3) << 9));
+    gl_t tw[8];
+    const gl_t *tp = A.ftw2 + t;
+#pragma unroll
+    for (int e = 0; e < 8; e++) tw[e] = tp[e * NTT_THREADS];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = lds[p0 ^ pidx2((uint32_t)i << 6)];
+    dft_regs<3, 0, INV>(v);
+    static_for<0, 8>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      v[i] = gl_mul(v[i], tw[brev_c(i, 3)]);
+    });
+#pragma unroll
+    for (int i = 0; i < 8; i++) lds[p0 ^ pidx2((uint32_t)i << 6)] = v[i];
+  }
+  asm volatile("" ::: "memory");  // the same wave, the same 512 elements (bits 0-2 = w)
+  {  // bits 3-5: element = w + 8 j + 64 l; output j takes w_64^-(w brev(j))
+    const uint32_t p0 = pidx2(w | (l << 6));
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = lds[p0 ^ pidx2((uint32_t)j << 3)];
+    dft_regs<3, 0, INV>(v);
+    shift_twiddles_k<INV, 3, 3>(v, w);
+#pragma unroll
+    for (int j = 0; j < 8; j++) lds[p0 ^ pidx2((uint32_t)j << 3)] = v[j];
+  }
+  __syncthreads();
+  {
+    const uint32_t p0 = pidx2(8 * t);
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = lds[p0 ^ (uint32_t)k];
+  }
+  dft_regs<3, 0, INV>(v);  // bits 0-2: no twiddles
+  if (A.post != 1) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = gl_mul(v[k], A.post);
+  }
+  ulonglong2 *d2 = reinterpret_cast<ulonglong2 *>(dst + tbase + 8 * t);
+#pragma unroll
+  for (int i = 0; i < 4; i++) d2[i] = make_ulonglong2(v[2 * i], v[2 * i + 1]);
+}
+
 static inline size_t lds_bytes(uint32_t TB) { return std::max<size_t>((size_t)1 << TB, 256) * sizeof(gl_t); }  // no padding: pidx() is a permutation of every 256-element block
 
 // ---- plan -----------------------------------------------------------------------
@@ -825,7 +1007,7 @@ NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse) {
       beta += rr[i];
     }
     // the direct form (DIT, full tiles): the 12-layer head [3,3,3,3], strided passes [3], [3,2], [3,3], [3,2,2], [3,3,2], [3,3,3]
-    if (dit && !inverse && NTT_TILE_BITS == 12 && NTT_PER == 8 && ps.a + ps.tb == 12 && np.r[0] == 3 &&
+    if (((dit && !inverse) || (!dit && inverse)) && NTT_TILE_BITS == 12 && NTT_PER == 8 && ps.a + ps.tb == 12 && np.r[0] == 3 &&
         (ps.s == 0 ? (ps.a == 12) : (ps.a == 3 || (ps.a >= 5 && ps.a <= 9)))) {
       np.direct = true;
       if (np.nrounds >= 2) {
@@ -1007,7 +1189,25 @@ static void ntt_passes(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_
       const NttPass &ps = plan->passes[i];
       const uint32_t rm = ps.nrounds == 3 ? ps.r[1] : 0, rl = ps.nrounds >= 2 ? ps.r[ps.nrounds - 1] : 0;
       // (profile names = rocprofv3's demangled symbols)
-      if (ps.s == 0 && head2_on()) {
+      if (!plan->dit) {
+        if (ps.s == 0) {
+          ProfScope psd("ntt_dif_tail2_kernel<true>", bytes);
+          hipLaunchKernelGGL((ntt_dif_tail2_kernel<true>), grid, dim3(NTT_THREADS), lb, st, A);
+        } else {
+#define P2_STRIDED_DIF(RM, RL)                                                                                    \
+  do {                                                                                                            \
+    ProfScope psd("ntt_dif_strided_kernel<true, " #RM ", " #RL ">", bytes);                                       \
+    hipLaunchKernelGGL((ntt_dif_strided_kernel<true, RM, RL>), grid, dim3(NTT_THREADS), (RL) ? lb : 0, st, A);     \
+  } while (0)
+          if (rm == 0 && rl == 0) P2_STRIDED_DIF(0, 0);
+          else if (rm == 0 && rl == 2) P2_STRIDED_DIF(0, 2);
+          else if (rm == 0 && rl == 3) P2_STRIDED_DIF(0, 3);
+          else if (rm == 2 && rl == 2) P2_STRIDED_DIF(2, 2);
+          else if (rm == 3 && rl == 2) P2_STRIDED_DIF(3, 2);
+          else P2_STRIDED_DIF(3, 3);
+#undef P2_STRIDED_DIF
+        }
+      } else if (ps.s == 0 && head2_on()) {
         ProfScope psd("ntt_dit_head2_kernel<false>", bytes);
         hipLaunchKernelGGL((ntt_dit_head2_kernel<false>), grid, dim3(NTT_THREADS), lb, st, A);
       } else if (ps.s == 0) {

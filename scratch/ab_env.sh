@@ -10,7 +10,8 @@ import json, sys
 d = json.load(open("/tmp/ab_detail.json"))
 ks = d["kernel_ms_per_proof_lone"]
 lde = sum(v for k, v in ks.items() if k.startswith(("ntt_dit", "ntt_pass_kernel<1")))
-print(f"{sys.argv[1]:28s} value {d['value']:7.1f}  lone {d['latency_ms_single_proof']:6.3f} ms  host {d['value_host_witness']:6.1f}  LDE {lde:.3f}  " +
+intt = sum(v for k, v in ks.items() if k.startswith(("ntt_dif", "ntt_pass_kernel<0")))
+print(f"{sys.argv[1]:28s} value {d['value']:7.1f}  lone {d['latency_ms_single_proof']:6.3f} ms  host {d['value_host_witness']:6.1f}  LDE {lde:.3f} iNTT {intt:.3f}  " +
       "  ".join(f"{k.split('(')[0][:34]} {v:.3f}" for k, v in list(ks.items())[:6]))
 PY
 }

@@ -126,6 +126,8 @@ def test_direct_dit_passes_match_oracle(pkg, orc, gpu, d):
     rate = 3 if d <= 17 else 1
     lde = pkg.lde_batch(v, rate)
     assert np.array_equal(lde, np.stack([orc.coset_lde(r, rate) for r in v]))
+    # ... and their mirror images for values -> coefficients (ntt_dif_strided_kernel, ntt_dif_tail2_kernel)
+    assert np.array_equal(pkg.ifft_batch(v), np.stack([orc.ntt(r, inverse=True) for r in v]))
 
 
 def test_ab_switches_keep_every_byte(gpu):
@@ -149,6 +151,7 @@ P = 0xFFFFFFFF00000001
 for d in (12, 15, 17, 19, 21):
     v = rng.integers(0, P, size=(2, 1 << d), dtype=np.uint64)
     print("LDE", d, hashlib.sha256(pkg.lde_batch(v, 3 if d <= 17 else 1).tobytes()).hexdigest())
+    print("LDE-ifft", d, hashlib.sha256(pkg.ifft_batch(v).tobytes()).hexdigest())
 for d, mix in ((8, "sha"), (11, "sha"), (14, "ecdsa")):
     blob, wires = pkg.make_circuit(d, mix, 5)
     cd = pkg.CircuitData(blob)
@@ -161,7 +164,7 @@ for d, mix in ((8, "sha"), (11, "sha"), (14, "ecdsa")):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("LDE", "PROOF"))])
-    assert len(outs[0]) == 11 and outs[0] == outs[1] == outs[2] == outs[3]
+    assert len(outs[0]) == 16 and outs[0] == outs[1] == outs[2] == outs[3]
 
 
 @pytest.mark.parametrize("d", [21, 22])

@@ -226,6 +226,7 @@ struct CircuitState {
   DBuf<uint32_t> wire_clean;          // [W] across proofs: 1 = wires.coeffs / wires.lde of the column hold zeros already
   int zero_columns = 1;               // knob "zero_columns": do not transform structured wire columns (classes 0 and 1)
   bool structured_off = false;        // a proof on this handle found every wire column dense: stop classifying
+  uint32_t last_dense = 0;            // dense wire columns of the previous proof (0: none yet): profile accounting (ColHints::dense_hint)
   uint32_t gate_wires = 0;            // wires [0, gate_wires) are what the gates of the circuit can read (max over the gate table)
   int virtual_columns = 1;            // knob "virtual_columns": structured columns >= max(R, gate_wires) get no LDE in memory (VirtCols)
   // tables

@@ -75,6 +75,8 @@ struct ColHints {
   size_t basis_stride = 0;
   uint32_t virt_first = UINT32_MAX; // columns >= virt_first (relative to cls) of class 0 / 1 are not stored at all: their
                                     // consumers recompute val[c] * basis on the fly (VirtCols)
+  uint32_t dense_hint = 0;          // profile accounting only: how many of the columns are dense (the handle's previous proof;
+                                    // 0 = not known -- the transforms' bytes are then counted for every column)
 };
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
                const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm = CosetMap(), uint32_t stride_cols = 0,

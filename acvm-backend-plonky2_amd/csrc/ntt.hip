@@ -1101,14 +1101,19 @@ __global__ __launch_bounds__(256) void structured_fill_kernel(gl_t *dst, uint32_
 }
 
 static void ntt_passes(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
-                       const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_all, const uint32_t *colnz);
+                       const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_all, const uint32_t *colnz,
+                       uint32_t dense = 0);
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
                const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_cols, const ColHints *hints) {
   if (cols == 0) return;
   if (hints) {
     const size_t n = (size_t)1 << plan->d;
     const uint32_t bx = (uint32_t)std::max<size_t>(1, n / (256 * 4));
-    ProfScope ps("structured_fill_kernel", 8.0 * cols * cosets * (double)n);
+    // (profile bytes: the structured columns that are actually stored -- those below virt_first; with no dense count from an earlier
+    // proof every column is counted)
+    const uint32_t stored = hints->virt_first < cols ? hints->virt_first : cols;
+    const uint32_t filled = hints->dense_hint && hints->dense_hint <= cols ? (stored > hints->dense_hint ? stored - hints->dense_hint : 0) : cols;
+    ProfScope ps("structured_fill_kernel", 8.0 * filled * cosets * (double)n);
     hipLaunchKernelGGL(structured_fill_kernel, dim3(bx, cols), dim3(256), 0, st, dst, plan->d,
                        stride_cols ? stride_cols : cols, cosets, *hints, cm.first, cm.stride);
   }
@@ -1134,7 +1139,8 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
       return;
     }
   }
-  ntt_passes(st, plan, src, dst, cols, cosets, scale, post, src_per_coset, cm, stride_all, colnz);
+  ntt_passes(st, plan, src, dst, cols, cosets, scale, post, src_per_coset, cm, stride_all, colnz,
+             hints && hints->dense_hint && hints->dense_hint <= cols ? hints->dense_hint : 0);
 }
 static void fill_pass_args(PassArgs &A, const NttPlan *plan, size_t i, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
                            const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_all, const uint32_t *colnz) {
@@ -1172,7 +1178,8 @@ static const char *pass_kernel_name(const NttPlan *plan, bool full) {
 // round 4, bit-exact, and measured slower and heavier on HBM than two launches: profiles/r04_lde_fused.md; removed in round 5,
 // `git show 33c653e:acvm-backend-plonky2_amd/csrc/ntt.hip` has it.)
 static void ntt_passes(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
-                       const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_all, const uint32_t *colnz) {
+                       const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm, uint32_t stride_all, const uint32_t *colnz,
+                       uint32_t dense) {
   const uint32_t d = plan->d;
   const size_t np = plan->passes.size();
   for (size_t i = 0; i < np; i++) {
@@ -1183,7 +1190,8 @@ static void ntt_passes(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_
     const uint32_t threads = TB >= 8 ? 256 : 64;
     // expected HBM bytes: every output element is written once; the input is read once per element, except
     // that the cosets of one (tile, column) share their source through one XCD's L2 (first LDE pass)
-    const double bytes = 8.0 * (double)cols * ((size_t)1 << d) * (cosets + (A.src_single ? 1.0 : (double)cosets));
+    // (structured columns are skipped by the kernels: `dense`, when the caller knows it, is what the launch really transforms)
+    const double bytes = 8.0 * (double)(dense ? dense : cols) * ((size_t)1 << d) * (cosets + (A.src_single ? 1.0 : (double)cosets));
     const size_t lb = lds_bytes(TB);
     if (plan->passes[i].direct && direct_on()) {
       const NttPass &ps = plan->passes[i];

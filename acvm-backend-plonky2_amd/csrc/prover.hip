@@ -457,6 +457,7 @@ ColHints wire_hints(const p2gpu_circuit *c, uint32_t col0, bool lde) {
   h.basis_stride = lde ? (size_t)c->C * c->n : c->n;
   const uint32_t vf = virt_first(c);
   if (lde && vf != UINT32_MAX) h.virt_first = vf > col0 ? vf - col0 : 0;
+  h.dense_hint = col0 == 0 ? c->last_dense : 0;
   return h;
 }
 // the unmaterialised columns of batch b for its leaf hash (only the wires have any)
@@ -777,6 +778,7 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     // at 2^20 rows, what fewer than 5 % structured columns give back; the knob "zero_columns" = 1 makes it look
     // again.  (Every column is then transformed like a dense one, which is always correct.)
     if (dense_count && (uint64_t)(c->W - *dense_count) * 20u < c->W) c->structured_off = true;
+    if (dense_count) c->last_dense = *dense_count;
     for (size_t j = 0; j < nall + K; j++) {
       gl_t a0 = 0, a1 = 0;
       for (uint32_t p = 0; p < parts; p++) {

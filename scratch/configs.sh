@@ -1,17 +1,19 @@
 #!/bin/bash
-# every configuration of DESIGN.md / profiles/NUMBERS.md on one box -> gpurun_out/r04_cfg/*.json   (copied to profiles/r04_bench*.json)
-O=gpurun_out/r04_cfg; mkdir -p $O
-j() { grep "^{" | tail -1; }
-python bench.py 2> $O/bench.err | j > $O/bench.json
-python bench.py --public-inputs 4 --no-cpu-baseline --no-cold-process 2>/dev/null | j > $O/bench_pi4.json
-python bench.py --mix ecdsa --no-cpu-baseline --no-cold-process 2>/dev/null | j > $O/bench_d17_ecdsa.json
-python bench.py --degree-bits 13 --mix arith --no-cpu-baseline --no-cold-process --steps 64 2>/dev/null | j > $O/bench_d13_arith.json
-python bench.py --degree-bits 19 --mix ecdsa --no-cpu-baseline --no-cold-process --steps 8 --warmup 4 --pipelined 0 2>/dev/null | j > $O/bench_d19_ecdsa.json
-python bench.py --degree-bits 21 --mix sha --no-cpu-baseline --steps 4 --warmup 1 --pipelined 0 --profile-steps 2 2>/dev/null | j > $O/bench_d21_sha.json
-python bench.py --degree-bits 21 --mix grammar --no-cpu-baseline --steps 4 --warmup 1 --pipelined 0 --profile-steps 2 2>/dev/null | j > $O/bench_d21_grammar.json
-python bench.py --hasher poseidon --no-cpu-baseline --no-cold-process --steps 12 --warmup 3 2>/dev/null | j > $O/bench_poseidon.json
-python bench.py --group 0,0 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | j > $O/bench_group2_same_gpu.json
-python bench.py --workload sha256 --no-cpu-baseline --no-cold-process 2>/dev/null | j > $O/bench_sha256x4.json
+# every configuration of DESIGN.md / profiles/NUMBERS.md on one box -> gpurun_out/<tag>_cfg/: the full results (bench.py --detail; copied to
+# profiles/<tag>_bench*.json) and the stdout lines (copied to profiles/<tag>_line*.json)          usage: bash scratch/configs.sh r05
+T=${1:-r05}; O=gpurun_out/${T}_cfg; mkdir -p $O
+b() { name=$1; shift; python bench.py --detail $O/bench$name.json "$@" 2> $O/bench$name.err | grep "^{" | tail -1 > $O/line$name.json; }
+b ""
+b _pi4 --public-inputs 4 --no-cpu-baseline --no-cold-process
+b _d17_ecdsa --mix ecdsa --no-cpu-baseline --no-cold-process
+b _d13_arith --degree-bits 13 --mix arith --no-cpu-baseline --no-cold-process --steps 64
+b _d19_ecdsa --degree-bits 19 --mix ecdsa --no-cpu-baseline --no-cold-process --steps 8 --warmup 4 --pipelined 0
+b _d21_sha --degree-bits 21 --mix sha --no-cpu-baseline --steps 4 --warmup 1 --pipelined 0 --profile-steps 2
+b _d21_grammar --degree-bits 21 --mix grammar --no-cpu-baseline --steps 4 --warmup 1 --pipelined 0 --profile-steps 2
+b _poseidon --hasher poseidon --no-cpu-baseline --no-cold-process --steps 12 --warmup 3
+b _group2_same_gpu --group 0,0 --steps 8 --warmup 2 --no-cpu-baseline
+b _sha256x4 --workload sha256 --no-cpu-baseline --no-cold-process
 # two ranks sharing the one GPU (gloo): the whole multi-rank flow -- replicas, one sharded proof over the ranks, the device-group probe
-python bench.py --gpus 2 --backend gloo --steps 16 --warmup 4 2>/dev/null | j > $O/bench_gloo2.json
+b _gloo2 --gpus 2 --backend gloo --steps 16 --warmup 4
+rm -f $O/*.err
 ls -la $O

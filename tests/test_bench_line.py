@@ -93,4 +93,6 @@ def test_committed_bench_lines_of_this_round_fit():
         lines = [ln for ln in open(p).read().splitlines() if ln.strip()]
         assert len(lines) == 1 and len(lines[0]) < 8000, p
         d = json.loads(lines[0])
-        assert d["roofline"]["frac"] <= 1.0 and "cpu_baseline" in d or d["n_gpus"] > 1, p
+        assert 0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["bound"] in ("hbm", "mfma"), p
+        if re.match(r"r\d+_line\.json$", os.path.basename(p)):     # the driver's command: the side configurations skip the CPU legs
+            assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] >= 1, p

@@ -216,9 +216,25 @@ __global__ __launch_bounds__(256, P2_QUOT_WAVES) void quotient_kernel(const Quot
     const gl_t bx0 = gl_mul(a.betas[0], x), bx1 = gl_mul(a.betas[1], x);
     const uint32_t t_base = out.t;
     for (uint32_t m = 0; m < a.nchunks; m++) {
-      uint64_t n0 = 1, d0 = 1, n1 = 1, d1 = 1;  // running products: congruent u64s, only ever multiplied (gl.hpp _nc)
-#pragma unroll 8
-      for (uint32_t j = m * a.QF; j < (m + 1) * a.QF && j < a.R; j++) {
+      // running products: congruent u64s, only ever multiplied (gl.hpp _nc).  They START at the chunk's first factor (every chunk
+      // has one: nchunks = ceil(R / QF)) instead of at 1: four products less per chunk, 40 of ~900 per row
+      uint64_t n0, d0, n1 = 1, d1 = 1;
+      {
+        const uint32_t j = m * a.QF;
+        const gl_t wv = wl[(size_t)j * n];
+        const gl_t sg = cs[(size_t)(a.NC + j) * n];
+        const gl_t kj = a.k_is[j];
+        const gl_t wg0 = gl_add(wv, a.gammas[0]);
+        n0 = gl_mul_add_nc(bx0, kj, wg0);
+        d0 = gl_mul_add_nc(a.betas[0], sg, wg0);
+        if (a.K > 1) {
+          const gl_t wg1 = gl_add(wv, a.gammas[1]);
+          n1 = gl_mul_add_nc(bx1, kj, wg1);
+          d1 = gl_mul_add_nc(a.betas[1], sg, wg1);
+        }
+      }
+#pragma unroll 7
+      for (uint32_t j = m * a.QF + 1; j < (m + 1) * a.QF && j < a.R; j++) {
         const gl_t wv = wl[(size_t)j * n];
         const gl_t sg = cs[(size_t)(a.NC + j) * n];
         const gl_t kj = a.k_is[j];

@@ -1114,8 +1114,13 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     const uint32_t stored = hints->virt_first < cols ? hints->virt_first : cols;
     const uint32_t filled = hints->dense_hint && hints->dense_hint <= cols ? (stored > hints->dense_hint ? stored - hints->dense_hint : 0) : cols;
     ProfScope ps("structured_fill_kernel", 8.0 * filled * cosets * (double)n);
-    hipLaunchKernelGGL(structured_fill_kernel, dim3(bx, cols), dim3(256), 0, st, dst, plan->d,
-                       stride_cols ? stride_cols : cols, cosets, *hints, cm.first, cm.stride);
+    // Columns at or above virt_first are stored only when they are dense (the transform kernels) or of class 3, and class 3 exists
+    // only with more than one special row (public-input circuits): otherwise the grid stops at virt_first -- 80 instead of 234
+    // column rows of blocks for a circuit without ECC gates, most of which would only look at their class and leave
+    const uint32_t fill_cols = hints->nrows > 1 ? cols : std::min(cols, hints->virt_first);
+    if (fill_cols)
+      hipLaunchKernelGGL(structured_fill_kernel, dim3(bx, fill_cols), dim3(256), 0, st, dst, plan->d,
+                         stride_cols ? stride_cols : cols, cosets, *hints, cm.first, cm.stride);
   }
   const uint32_t d = plan->d;
   const size_t np = plan->passes.size();

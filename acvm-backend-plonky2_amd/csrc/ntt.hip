@@ -1,4 +1,4 @@
-// ntt.hip -- batched Goldilocks NTT for gfx950: LDS-tiled passes, radix-16/8/4/2
+// ntt.hip -- batched Goldilocks NTT for gfx950: LDS-tiled passes, radix-8/4/2
 // register rounds with shift twiddles.
 //
 // Replaces (inside `circuit_data.prove`, plonky2-backend/src/actions/prove_action.rs:96)

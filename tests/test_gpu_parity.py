@@ -1034,10 +1034,10 @@ def test_other_cap_heights_and_pow_bits(pkg, orc, gpu, d, mix, cap_h, pow_bits, 
     oc.close()
 
 
-@pytest.mark.parametrize("env", [{"P2GPU_COOP_TAIL": "0"}, {"P2GPU_HOST_PRESCAN": "0"}])
+@pytest.mark.parametrize("env", [{"P2GPU_HOST_PRESCAN": "0"}, {"P2GPU_NTT_DIRECT": "0", "P2GPU_LEAF_LEVELS": "0"}])
 def test_measurement_switches_keep_the_bytes(pkg, gpu, env):
-    """The A/B switches DESIGN.md quotes select the older kernels / paths (one lane per node in the tree tops, the whole wire
-    matrix over PCIe): read once per process, so a child process proves a golden circuit with the switch set and the digest
+    """The A/B switches select the older kernels / paths (the whole wire matrix over PCIe; the generic NTT passes and no tree
+    levels inside the leaf hash -- the one-lane tree tails of rounds 1-2 behind P2GPU_COOP_TAIL left the tree in round 5): read once per process, so a child process proves a golden circuit with the switch set and the digest
     must still be the committed one."""
     import subprocess
     import sys

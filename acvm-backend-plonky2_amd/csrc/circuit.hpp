@@ -260,6 +260,8 @@ struct CircuitState {
   void *shard_ctx = nullptr;
   void *rccl_comm = nullptr;              // ncclComm_t: RCCL transport, collectives on `stream`
   int shard_exercise = 0;                 // run the exchange steps even with world = 1 (plumbing test)
+  int shard_intt = 0;                     // knob: column-sharded inverse transforms of the wires / Z-PP + all-gather of the coefficient
+                                          // blocks instead of the replicated transform; same bytes either way
   DBuf<gl_t> xchg_recv;
   // ONE process driving several GPUs (p2gpu_init with n > 1 device ids): the handle the caller holds is rank 0 of a
   // group and owns ranks 1..; every prove call fans out over one host thread per rank, and the exchanges of the

@@ -77,6 +77,8 @@ struct ColHints {
                                     // consumers recompute val[c] * basis on the fly (VirtCols)
   uint32_t dense_hint = 0;          // profile accounting only: how many of the columns are dense (the handle's previous proof;
                                     // 0 = not known -- the transforms' bytes are then counted for every column)
+  bool fill_only = false;           // write the structured columns and return: the dense ones are somebody else's (a rank of a
+                                    // sharded proof transforms only its block of the dense columns, prover.hip shard_intt)
 };
 void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, uint32_t cols, uint32_t cosets,
                const gl_t *scale, gl_t post, bool src_per_coset, CosetMap cm = CosetMap(), uint32_t stride_cols = 0,

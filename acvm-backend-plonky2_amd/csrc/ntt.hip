@@ -1121,6 +1121,7 @@ void ntt_batch(hipStream_t st, const NttPlan *plan, const gl_t *src, gl_t *dst, 
     if (fill_cols)
       hipLaunchKernelGGL(structured_fill_kernel, dim3(bx, fill_cols), dim3(256), 0, st, dst, plan->d,
                          stride_cols ? stride_cols : cols, cosets, *hints, cm.first, cm.stride);
+    if (hints->fill_only) return;
   }
   const uint32_t d = plan->d;
   const size_t np = plan->passes.size();

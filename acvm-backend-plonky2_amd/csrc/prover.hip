@@ -331,6 +331,109 @@ int shard_allgather(p2gpu_circuit *c, const void *send_dev, void *recv_dev, size
   ProfScope ps(exchange_name(bytes), (double)bytes * (double)(c->shard_world > 0 ? c->shard_world : 1));
   return shard_allgather_impl(c, send_dev, recv_dev, bytes);
 }
+// All-gather of blocks of DIFFERENT sizes, in place: on every rank the block of rank p lives at base + off[p] (sz[p] bytes, the
+// same off / sz on all ranks; a rank sends its own block and receives the others where they belong).  The exchange of the
+// column-sharded inverse transforms: each rank's block of coefficient columns goes straight into the
+// peers' coefficient buffers -- no staging, no unpack pass.
+//   device group: one hipMemcpyPeerAsync per peer on the sender's stream (all links of a rank at once);
+//   RCCL: one grouped ncclSend / ncclRecv pair per peer, sizes per peer;
+//   host callback (fixed-size all-gather, the gloo tests): pieces staged through xchg_recv.
+static int shard_allgatherv_impl(p2gpu_circuit *c, uint8_t *base, const size_t *off, const size_t *sz) {
+  const int world = c->shard_world, q = c->shard_rank;
+  if (c->peer) {
+    PeerGroup &g = *c->peer;
+    auto failed = [] {
+      set_err("another rank of the device group failed");
+      return P2GPU_E_DEVICE;
+    };
+    g.recv_ptr[q] = base;
+    HIP_TRY(hipEventRecord(g.recv_free[q], c->stream));
+    if (!g.barrier()) return failed();
+    for (int p = 0; p < g.n; p++) {
+      if (p == q) continue;
+      HIP_TRY(hipStreamWaitEvent(c->stream, g.recv_free[p], 0));
+      if (sz[q]) HIP_TRY(hipMemcpyPeerAsync((uint8_t *)g.recv_ptr[p] + off[q], g.cs[p]->device, base + off[q], c->device, sz[q], c->stream));
+    }
+    HIP_TRY(hipEventRecord(g.sent[q], c->stream));
+    if (!g.barrier()) return failed();
+    for (int p = 0; p < g.n; p++)
+      if (p != q) HIP_TRY(hipStreamWaitEvent(c->stream, g.sent[p], 0));
+    return 0;
+  }
+  if (c->rccl_comm) {
+    const RcclApi &r = rccl();
+    if (world == 1) return 0;  // one rank: its block is in place
+    if (!(r.Send && r.Recv && r.GroupStart && r.GroupEnd)) {
+      set_err("librccl.so.1 has no ncclSend / ncclRecv: shard_intt needs them");
+      return P2GPU_E_DEVICE;
+    }
+    RCCL_TRY(r.GroupStart());
+    ncclResult_t bad = ncclSuccess;
+    const char *what = "";
+    for (int p = 0; p < world && bad == ncclSuccess; p++) {
+      if (p == q) continue;
+      if (sz[q]) {
+        bad = r.Send(base + off[q], sz[q], ncclUint8, p, (ncclComm_t)c->rccl_comm, c->stream);
+        what = "ncclSend";
+        if (bad != ncclSuccess) break;
+      }
+      if (sz[p]) {
+        bad = r.Recv(base + off[p], sz[p], ncclUint8, p, (ncclComm_t)c->rccl_comm, c->stream);
+        what = "ncclRecv";
+      }
+    }
+    const ncclResult_t ge = r.GroupEnd();  // (a failure inside the group still closes it)
+    if (bad != ncclSuccess) {
+      set_err("%s failed inside the grouped exchange: %s", what, r.GetErrorString(bad));
+      return P2GPU_E_DEVICE;
+    }
+    RCCL_TRY(ge);
+    return 0;
+  }
+  // host callback: equal-sized pieces, [send piece][world x piece] in xchg_recv
+  size_t mx = 0;
+  for (int p = 0; p < world; p++) mx = std::max(mx, sz[p]);
+  const size_t cap = (c->xchg_recv.count * sizeof(gl_t) / (size_t)(world + 1)) & ~(size_t)63;
+  if (!cap) {
+    set_err("internal: exchange staging buffer too small");
+    return P2GPU_E_DEVICE;
+  }
+  uint8_t *stage = (uint8_t *)c->xchg_recv.p, *recv = stage + cap;
+  for (size_t done = 0; done < mx; done += cap) {
+    const size_t piece = std::min(cap, mx - done);
+    if (sz[q] > done) HIP_TRY(hipMemcpyAsync(stage, base + off[q] + done, std::min(piece, sz[q] - done), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = c->shard_fn(c->shard_ctx, (uint64_t)(uintptr_t)stage, (uint64_t)(uintptr_t)recv, (uint64_t)piece);
+    if (rc) {
+      set_err("all-gather callback failed (%d)", rc);
+      return P2GPU_E_DEVICE;
+    }
+    for (int p = 0; p < world; p++)
+      if (p != q && sz[p] > done)
+        HIP_TRY(hipMemcpyAsync(base + off[p] + done, recv + (size_t)p * piece, std::min(piece, sz[p] - done), hipMemcpyDeviceToDevice, c->stream));
+  }
+  return 0;
+}
+int shard_allgatherv(p2gpu_circuit *c, uint8_t *base, const size_t *off, const size_t *sz) {
+  size_t total = 0, mx = 0;
+  for (int p = 0; p < c->shard_world; p++) {
+    total += sz[p];
+    mx = std::max(mx, sz[p]);
+  }
+  ProfScope ps(exchange_name(mx), (double)total);
+  return shard_allgatherv_impl(c, base, off, sz);
+}
+// Blocks of the column-sharded inverse transform: the dense columns (sorted list `dense`, nd of them) are dealt out in G
+// contiguous runs of the list, sizes differing by at most one; rank p's BLOCK is the column range from the first to the last
+// column of its run (structured columns in between travel with it: they hold what the receiver's own fill writes anyway).
+// parallel.intt_blocks restates this for the exchange plan.
+void intt_blocks(const uint32_t *dense, uint32_t nd, uint32_t G, uint32_t *lo, uint32_t *hi) {
+  for (uint32_t p = 0; p < G; p++) {
+    const uint32_t s = (uint32_t)((uint64_t)p * nd / G), e = (uint32_t)((uint64_t)(p + 1) * nd / G);
+    lo[p] = e > s ? dense[s] : 0;
+    hi[p] = e > s ? dense[e - 1] + 1 : 0;
+  }
+}
 // does this proof go through the exchange steps?  (world 1 + "shard_exercise": the same code with one
 // rank, which is how the RCCL plumbing is exercised on a single-GPU box)
 bool sharded(const p2gpu_circuit *c) { return c->shard_world > 1 || (c->shard_exercise && (c->rccl_comm || c->shard_fn || c->peer)); }
@@ -513,6 +616,50 @@ int batch_commit_from_values(p2gpu_circuit *c, Batch &b, const gl_t *vals_dev) {
     }
     gl_t ninv = gl_inv((gl_t)c->n);
     const ColHints h = nz ? wire_hints(c, 0, false) : ColHints();
+    if (c->shard_intt && sharded(c)) {
+      // SURVEY 8(e) steps 1-2 (knob "shard_intt"): rank q transforms only ITS block of the dense columns and the coefficient
+      // blocks are all-gathered in place; structured columns are written locally on every rank (no exchange for them).
+      // The ranks agree on the blocks without talking: the witness is replicated, so the column classes are too.
+      const uint32_t G = (uint32_t)c->shard_world, q = (uint32_t)c->shard_rank, cols = b.cols;
+      std::vector<uint32_t> dense;
+      dense.reserve(cols);
+      if (nz) {
+        uint32_t *hc = c->pin.take<uint32_t>(cols);
+        if (!hc) return pin_exhausted();
+        HIP_TRY(hipMemcpyAsync(hc, nz, 4 * (size_t)cols, hipMemcpyDeviceToHost, c->stream));
+        if (int rc_ = wait_stream(c)) return rc_;
+        for (uint32_t j = 0; j < cols; j++)
+          if (hc[j] == 2u) dense.push_back(j);
+      } else {
+        for (uint32_t j = 0; j < cols; j++) dense.push_back(j);
+      }
+      uint32_t lo[8], hi[8];
+      size_t off[8], sz[8];
+      intt_blocks(dense.data(), (uint32_t)dense.size(), G, lo, hi);
+      for (uint32_t p = 0; p < G; p++) {
+        off[p] = 8 * (size_t)lo[p] * c->n;
+        sz[p] = 8 * (size_t)(hi[p] - lo[p]) * c->n;
+      }
+      auto part = [&](uint32_t c0, uint32_t c1, bool fill_only) {
+        if (c1 <= c0 || (fill_only && !nz)) return;
+        ColHints hp = nz ? wire_hints(c, c0, false) : ColHints();
+        hp.fill_only = fill_only;
+        hp.dense_hint = 0;
+        ntt_batch(c->stream, c->plan_inv, vals_dev + (size_t)c0 * c->n, b.coeffs.p + (size_t)c0 * c->n, c1 - c0, 1, nullptr, ninv, false,
+                  CosetMap(), 0, nz ? &hp : nullptr);
+      };
+      if (hi[q] > lo[q]) {
+        part(0, lo[q], true);
+        part(lo[q], hi[q], false);
+        part(hi[q], cols, true);
+      } else {
+        part(0, cols, true);
+      }
+      TRACE(c, "  inverse ntt (own block)");
+      if (int rc = shard_allgatherv(c, (uint8_t *)b.coeffs.p, off, sz)) return rc;
+      TRACE(c, "  coefficient blocks exchanged");
+      return batch_commit_from_coeffs(c, b);
+    }
     ntt_batch(c->stream, c->plan_inv, vals_dev, b.coeffs.p, b.cols, 1, nullptr, ninv, false, CosetMap(), 0, nz ? &h : nullptr);
   }
   TRACE(c, "  inverse ntt");
@@ -1670,7 +1817,7 @@ static int circuit_create_one(const uint8_t *blob, size_t len, int device, p2gpu
     // the alpha powers of the openings (2 * nall words), the opening partials, the final polynomial, the query gather
     const size_t caps = (size_t)2 * (4 + c->n_steps) * (sizeof(dig_t) << c->cap_h);
     CK(c->pin.alloc(16 * c->gather_cap + 32 * n_final + 16 * (size_t)(nall + K) * 16 + 16 * (size_t)nall + 16 * (size_t)c->nterms +
-                    16 * (size_t)c->W + caps + ((size_t)1 << 18)),
+                    20 * (size_t)c->W + caps + ((size_t)1 << 18)),  // (4 W more: the column classes read back early by shard_intt)
        "alloc pinned staging");
   }
 
@@ -1734,6 +1881,7 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
   if (k == "pow_hint") c->pow_hint = value;
   else if (k == "self_check") c->self_check = (int)value;
   else if (k == "shard_exercise") c->shard_exercise = (int)value;
+  else if (k == "shard_intt") c->shard_intt = (int)value;
   else if (k == "blocking_sync") c->blocking_sync = (int)value;
   else if (k == "virtual_columns") {
     c->virtual_columns = (int)value;

@@ -101,11 +101,34 @@ def max_over_ranks(seconds, group=None):
     return float(t.item())
 
 
+def intt_blocks(dense, world_size):
+    """Column blocks of the column-sharded inverse transform (knob `shard_intt`; csrc/prover.hip intt_blocks): the sorted list of
+    dense columns is dealt out in `world_size` contiguous runs whose sizes differ by at most one; rank p's block is the column
+    range [first, last + 1) of its run -- what it transforms and what it sends (structured columns in between ride along).
+    -> [(lo, hi)] per rank, (0, 0) for a rank with no dense column."""
+    dense = sorted(dense)
+    nd, G = len(dense), world_size
+    out = []
+    for p in range(G):
+        s, e = p * nd // G, (p + 1) * nd // G
+        out.append((dense[s], dense[e - 1] + 1) if e > s else (0, 0))
+    return out
+
+
+def exchange_bytes(entry_bytes, world_size):
+    """(bytes the busiest rank sends, bytes over all ranks) of one plan entry: an int is an all-gather of equal blocks, a tuple
+    holds the per-rank bytes of an all-gather of unequal blocks (the coefficient blocks of `shard_intt`)."""
+    if isinstance(entry_bytes, tuple):
+        return max(entry_bytes), sum(entry_bytes)
+    return entry_bytes, entry_bytes * world_size
+
+
 def exchange_plan(degree_bits, world_size, num_wires=234, num_constants_sigmas=84, num_challenges=2, partial_products=9,
-                  quotient_degree_factor=8, rate_bits=3, cap_height=4, num_queries=28, host_witness=False, dense_columns=None):
+                  quotient_degree_factor=8, rate_bits=3, cap_height=4, num_queries=28, host_witness=False, dense_columns=None,
+                  shard_intt=False, dense_list=None):
     """The exchange steps of ONE coset-sharded proof (csrc/prover.hip shard_allgather call sites), in
     order: [(what, bytes each rank sends)].  Every step is an all-gather over the `world_size` ranks, so a rank receives
-    (world_size - 1) x those bytes; nothing else crosses between the GPUs.  Host-side restatement for tests and budgets: the
+    (world_size - 1) x those bytes (a tuple: unequal blocks, bytes per rank -- `exchange_bytes`); nothing else crosses between the GPUs.  Host-side restatement for tests and budgets: the
     GPU tests compare it with what the library counts (`profile` = 2: the exchange[...] pseudo-kernels of p2gpu_kernel_stats)."""
     d, G, K = degree_bits, world_size, num_challenges
     n, C = 1 << d, 1 << rate_bits
@@ -128,7 +151,15 @@ def exchange_plan(degree_bits, world_size, num_wires=234, num_constants_sigmas=8
         # exchanged.  Through p2gpu_prove_sparse (dense_columns < W: the caller says which wires are unused) every rank uploads
         # the dense columns itself and nothing is exchanged
         plan.append(("witness column blocks", 8 * -(-num_wires // G) * n))
+    if shard_intt:
+        # every rank runs the inverse transform of ITS block of the dense wire columns and the coefficient
+        # blocks are all-gathered in place (unequal blocks: a tuple of per-rank bytes); structured columns never travel unless they
+        # lie between two dense columns of one block.  dense_list: the dense wire columns (default: the first `dense_columns`)
+        dl = list(dense_list) if dense_list is not None else list(range(num_wires if dense_columns is None else dense_columns))
+        plan.append(("wires coefficient blocks", tuple(8 * (hi - lo) * n for lo, hi in intt_blocks(dl, G))))
     plan.append(("wires cap", cap_bytes))
+    if shard_intt:
+        plan.append(("Z / partial products coefficient blocks", tuple(8 * (hi - lo) * n for lo, hi in intt_blocks(range(nzp), G))))
     plan.append(("Z / partial products cap", cap_bytes))
     plan.append(("quotient interpolants", K * cl * n * 8))
     plan.append(("quotient cap", cap_bytes))
@@ -150,4 +181,4 @@ def exchange_budget(plan, world_size, link_gbps=153.0, latency_us=60.0):
     """Seconds of one sharded proof spent in its exchanges under a simple model: every rank drives all its world_size - 1 xGMI
     links at once (direct peer copies / grouped send-recv, not a ring), `latency_us` per exchange (measured between two ranks on one
     GPU: 60 us below 1 MB, profiles/NUMBERS.md), `link_gbps` per link and direction."""
-    return sum(latency_us * 1e-6 + b / (link_gbps * 1e9) for _, b in plan)
+    return sum(latency_us * 1e-6 + exchange_bytes(b, world_size)[0] / (link_gbps * 1e9) for _, b in plan)

@@ -168,6 +168,24 @@ def test_exchange_plan_of_a_sharded_proof(pkg, d, world):
     assert len(hw) == len(plan) + 1 and hw[0] == ("witness column blocks", 8 * -(-234 // G) * n) and hw[1:] == plan
     # ... the compact entry point (p2gpu_prove_sparse): every rank uploads the dense columns itself, nothing is exchanged
     assert pkg.parallel.exchange_plan(d, world, host_witness=True, dense_columns=80) == plan
+    # knob shard_intt: two more exchanges, the coefficient blocks of the column-sharded inverse transforms --
+    # unequal blocks, bytes per rank; only dense columns (and what lies between two of one block) travel
+    par = pkg.parallel
+    dense = list(range(80)) + list(range(135, 155))          # e.g. routed wires + a second run of gate wires
+    sp = par.exchange_plan(d, world, shard_intt=True, dense_list=dense)
+    assert [p[0] for p in sp] == ["wires coefficient blocks", "wires cap", "Z / partial products coefficient blocks"] + names[1:]
+    blocks = par.intt_blocks(dense, G)
+    owned = [[c for c in dense if lo <= c < hi] for lo, hi in blocks]
+    assert sum(owned, []) == dense and max(map(len, owned)) - min(map(len, owned)) <= 1
+    assert all(a[1] <= b[0] for a, b in zip(blocks, blocks[1:]) if b != (0, 0))      # disjoint, in order
+    wb = dict(sp)["wires coefficient blocks"]
+    assert isinstance(wb, tuple) and len(wb) == G and wb == tuple(8 * (hi - lo) * n for lo, hi in blocks)
+    assert 8 * len(dense) * n <= sum(wb) <= 8 * (len(dense) + 55) * n     # at most one gap (the 55 structured columns) rides along
+    zb = dict(sp)["Z / partial products coefficient blocks"]
+    assert sum(zb) == 8 * 20 * n and max(zb) == 8 * -(-20 // G) * n
+    assert par.exchange_bytes(wb, G) == (max(wb), sum(wb)) and par.exchange_bytes(64, G) == (64, 64 * G)
+    assert par.intt_blocks([], 4) == [(0, 0)] * 4 and par.intt_blocks([5], 2) == [(0, 0), (5, 6)]
+    assert par.exchange_budget(sp, world) > par.exchange_budget(plan, world)
     # budget: eight exchanges at ~60 us each + the interpolants over G - 1 links at once
     t = pkg.parallel.exchange_budget(plan, world)
     assert 8 * 60e-6 < t < 8 * 60e-6 + 2 * 8 * n * 8 / G / 153e9 + 1e-4

@@ -629,25 +629,35 @@ def _shard_worker(rank, world, port, d, mix, npi, q):
     blob, wires, pis = (out + ((),))[:3] if npi == 0 else out
     cd = pkg.CircuitData(blob)
     cd.set_shard(rank, world)
-    p1 = cd.prove(wires, public_inputs=pis).to_bytes()
-    p2 = cd.prove(torch.from_numpy(wires.view(np.int64)).cuda(), public_inputs=pis).to_bytes()
+    same = True
+    p1 = None
+    wd = torch.from_numpy(wires.view(np.int64)).cuda()
     # host witness in sharded mode: a rank reads only ITS block of columns -- the rest
     # of the matrix it is handed may be garbage, the blocks are all-gathered between the GPUs
     cpr = -(-wires.shape[0] // world)
     own = wires.copy()
     own[:rank * cpr] = 0xDEADBEEF
     own[(rank + 1) * cpr:] = 0xDEADBEEF
-    p3 = cd.prove(own, public_inputs=pis).to_bytes()
+    # knob shard_intt: the inverse transforms of the wires / Z-PP columns replicated (0) or column-sharded with an all-gather of
+    # the coefficient blocks (1) -- the same bytes either way, through every entry point, and with the column classes off
+    for intt, zc in ((0, 1), (1, 1), (1, 0), (0, 1)):
+        cd.set("shard_intt", intt)
+        cd.set("zero_columns", zc)
+        got = [cd.prove(wires, public_inputs=pis).to_bytes(), cd.prove(wd, public_inputs=pis).to_bytes(), cd.prove(own, public_inputs=pis).to_bytes()]
+        p1 = p1 or got[0]
+        same = same and got == [p1] * 3
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, p1, p1 == p2 == p3))
+    q.put((rank, p1, same))
 
 
-@pytest.mark.parametrize("world,d,mix,npi", [(2, 8, "ecdsa", 0), (2, 13, "sha", 4), (4, 9, "arith", 0), (8, 10, "ecdsa", 0)])
+@pytest.mark.parametrize("world,d,mix,npi", [(2, 8, "ecdsa", 0), (2, 13, "sha", 4), (4, 9, "arith", 0), (8, 10, "ecdsa", 0), (4, 11, "sha", 0),
+                                             (8, 12, "sha", 3), (8, 14, "grammar", 0), (2, 17, "sha", 0)])
 def test_coset_sharded_proof_matches_oracle(pkg, orc, gpu, world, d, mix, npi):
     """`world` processes (one per GPU on a real node; here they share the GPU and talk gloo) each
     keep 8/world LDE cosets of the per-proof oracles; caps, quotient interpolants and query
-    openings are all-gathered.  Every rank must return the oracle's proof bytes."""
+    openings are all-gathered -- and, with the knob `shard_intt`, the coefficient blocks of the column-sharded inverse
+    transforms.  Every rank must return the oracle's proof bytes."""
     import socket
 
     import torch.multiprocessing as mp
@@ -763,6 +773,9 @@ def test_rccl_transport_single_rank(pkg, orc, gpu, d, mix, npi):
     cd.set("shard_exercise", 1)
     got = cd.prove(wires, public_inputs=pis).to_bytes()
     assert got == plain == orc.OracleCircuit(blob).prove(wires, public_inputs=pis)[0]
+    cd.set("shard_intt", 1)     # one rank owns every block: the transform runs block-wise, the exchange has no peer
+    assert cd.prove(wires, public_inputs=pis).to_bytes() == plain
+    cd.set("shard_intt", 0)
     cd.set("shard_exercise", 0)
     assert cd.prove(wires, public_inputs=pis).to_bytes() == plain
     cd.close()
@@ -893,9 +906,10 @@ def test_exchange_plan_matches_the_library(pkg, gpu, world):
     def classes(plan):
         out = {"small": [0, 0], "mid": [0, 0], "big": [0, 0]}
         for _, b in plan:
-            k = "small" if b <= 4096 else ("mid" if b < (1 << 20) else "big")
+            mx, total = pkg.parallel.exchange_bytes(b, world)
+            k = "small" if mx <= 4096 else ("mid" if mx < (1 << 20) else "big")
             out[k][0] += 1
-            out[k][1] += b * world
+            out[k][1] += total
         return out
 
     try:
@@ -905,9 +919,17 @@ def test_exchange_plan_matches_the_library(pkg, gpu, world):
         hdr = blob[:256].view(np.uint32)
         cd = pkg.CircuitData(blob)
         wd = torch.from_numpy(wires.view(np.int64)).cuda()
-        for host, w, ncols in ((False, wd, None), (True, wires, None)):
+        # the dense wire columns as the library classifies them: anything that is non-zero outside the one row the unused wires share
+        wm = wires.reshape(int(hdr[3]), -1)
+        nzrows = [np.nonzero(col)[0] for col in wm]
+        single = [int(r[0]) for r in nzrows if len(r) == 1]
+        pi_row = max(set(single), key=single.count) if single else -1
+        dense_list = [j for j, r in enumerate(nzrows) if len(r) > 1 or (len(r) == 1 and int(r[0]) != pi_row)]
+        for host, w, ncols, intt in ((False, wd, None, 0), (True, wires, None, 0), (False, wd, None, 1), (True, wires, None, 1)):
+            cd.set("shard_intt", intt)
             plan = pkg.parallel.exchange_plan(d, world, num_wires=int(hdr[3]), num_constants_sigmas=int(hdr[5]) + int(hdr[4]), host_witness=host,
-                                              dense_columns=ncols)
+                                              dense_columns=ncols, shard_intt=bool(intt), dense_list=dense_list)
+            assert len(plan) == 8 + int(host) + 2 * intt
             want = classes(plan)
             cd.prove(w)
             cd.set("profile", 2)
@@ -958,6 +980,15 @@ def test_single_process_device_group(pkg, orc, gpu, world):
                 sp = cd.prove_sparse(np.ascontiguousarray(wm[:ncols]).reshape(-1), ncols, 0, public_inputs=pis, tail=np.ascontiguousarray(wm[ncols:, 0]))
                 assert sp.to_bytes() == want
             cd.verify(want)
+            # column-sharded inverse transforms: the coefficient blocks go rank to rank as peer copies, in place
+            cd.set("shard_intt", 1)
+            assert cd.prove(wires, public_inputs=pis).to_bytes() == want
+            assert cd.prove(wd, public_inputs=pis).to_bytes() == want
+            assert cd.prove_routed(np.ascontiguousarray(wires[:80]), public_inputs=pis).to_bytes() == want
+            cd.set("zero_columns", 0)
+            assert cd.prove(wd, public_inputs=pis).to_bytes() == want
+            cd.set("zero_columns", 1)
+            cd.set("shard_intt", 0)
             # an unsatisfied witness fails on every rank at the same point; the group is usable afterwards
             bad = wires.copy()
             bad[0, 1] = (int(bad[0, 1]) + 1) % P

@@ -242,6 +242,7 @@ struct CircuitState {
   Batch cs, wires, zp, quot;
   dig_t circuit_digest;
   gl_t poseidon_rc[360];
+  gl_t poseidon_rc_gate[360];  // poseidon_device_constants(poseidon_rc): what eval_poseidon_gate takes
   // work buffers
   DBuf<gl_t> wires_vals, zp_vals, cp, rowprod, scan_tmp, apow, qvals, qtmp, pw, partial, ext_apow, f01, f01v, fv;
   std::vector<DBuf<gl_t>> fri_coef, fri_vals;

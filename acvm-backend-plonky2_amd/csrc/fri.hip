@@ -372,18 +372,7 @@ __global__ __launch_bounds__(256) void pow_kernel(PowState st0, uint32_t pos, ui
   for (int j = 0; j < 12; j++)
     if ((uint32_t)j == pos) st[j] = w;
   if constexpr (H == 1) {  // Challenger<F, PoseidonHash>: the sponge permutation is Poseidon
-#pragma unroll 1
-    for (int r = 0; r < 30; r++) {
-      if (r < 4 || r >= 26) {
-#pragma unroll
-        for (int j = 0; j < 12; j++) st[j] = poseidon_sbox_nc(gl_add(st[j], prc[12 * r + j]));
-      } else {  // (prc = poseidon_device_constants)
-        st[0] = poseidon_sbox_nc(gl_add(st[0], prc[12 * r]));
-      }
-      poseidon_mds_dev(st);
-    }
-#pragma unroll
-    for (int j = 0; j < 12; j++) st[j] = gl_canon(st[j]);
+    poseidon_permute_dev(st, prc);  // (prc = poseidon_device_constants)
   } else {
     keccak_permutation12<8>(st);  // the response is word 7: the third layer of the onion (words 8..11) is never looked at
   }

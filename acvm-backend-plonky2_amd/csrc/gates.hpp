@@ -56,8 +56,8 @@ struct BaseOps {
     }
     P2_HD T value() const { return gl_reduce128(lo, hi); }
   };
-  // sum_i v_i k_i with small k_i (k_i < 2^20, < 2^10 terms): the two 32-bit halves of v are
-  // multiplied and summed separately in 64 bits (one v_mad_u64_u32 each), one reduction at the end
+  // sum_i v_i k_i with small k_i (sum of the k_i < 2^31: the fused Poseidon layers reach 2^24.2): the two 32-bit halves of v
+  // are multiplied and summed separately in 64 bits (one v_mad_u64_u32 each), one reduction at the end
   struct SmallDot {
     uint64_t lo = 0, hi = 0;
     P2_HD void add(T v, uint32_t k) {
@@ -129,13 +129,14 @@ P2_HD typename F::T ra_fold(WF &W, uint32_t item0, const typename F::T *bv) {
 }
 
 // PoseidonGate (plonky2 gates/poseidon.rs), on its own so that a kernel can evaluate just this gate.
+// prc: the round constants in the poseidon_device_constants form (in a partial round only word 0 has one; round 26
+// carries what the others owe) -- the S-box inputs, the only constrained points, are those of the plain form and of
+// upstream's fast factorisation, so all 123 constraint values coincide.  The 23 linear layers between the S-boxes of
+// round 3 and those of round 26 are applied three at a time (poseidon.hpp POSEIDON_FUSED: M, M P M, M P M P M).
+// Wires: in 0..11, out 12..23, swap 24, delta 25..28, full-0 S-box inputs 29.. (rounds 1-3), partial 65.., full-1 87..
 template <class F, class WF, class OUT>
 P2_HD void eval_poseidon_gate(WF W, const gl_t *prc, OUT &out) {
   typedef typename F::T T;
-  // plonky2 gates/poseidon.rs.  Partial rounds in plain form: the S-box inputs (the only
-  // non-linear points) equal those of upstream's fast factorisation, so all 123 constraint
-  // values coincide.  Wires: in 0..11, out 12..23, swap 24, delta 25..28, full-0 S-box
-  // inputs 29.. (rounds 1-3), partial 65.., full-1 87..
   T st[12];
   const T swap = W(24);
   out.emit(F::mul(swap, F::sub(swap, F::from(1))));
@@ -146,60 +147,127 @@ P2_HD void eval_poseidon_gate(WF W, const gl_t *prc, OUT &out) {
     st[i + 4] = F::sub(r, dl);
   }
   for (int i = 8; i < 12; i++) st[i] = W(i);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
-  for (int r = 0; r < 30; r++) {
+  // one full round: constants, (constraints against the S-box input wires), S-boxes; `layer`: also the linear layer
+  auto full_round = [&](int r, bool layer) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int i = 0; i < 12; i++) st[i] = F::add(st[i], F::from(prc[12 * r + i]));
-    const bool full = r < 4 || r >= 26;
-    if (full) {
-      if (r != 0) {
-        const uint32_t base = r < 4 ? 29 + 12 * (r - 1) : 87 + 12 * (r - 26);
+    if (r != 0) {
+      const uint32_t base = r < 4 ? 29 + 12 * (r - 1) : 87 + 12 * (r - 26);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int i = 0; i < 12; i++) {
-          const T sb = W(base + i);
-          out.emit(F::sub(st[i], sb));
-          st[i] = sb;
-        }
+      for (int i = 0; i < 12; i++) {
+        const T sb = W(base + i);
+        out.emit(F::sub(st[i], sb));
+        st[i] = sb;
       }
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-      for (int i = 0; i < 12; i++) st[i] = F::pow7_out(st[i]);  // consumed by the SmallDot rows below only
-    } else {
-      const T sb = W(65 + (r - 4));
-      out.emit(F::sub(st[0], sb));
-      st[0] = F::pow7_out(sb);
-    }
-    // MDS layer: out[row] = sum_i st[(i + row) % 12] * CIRC[i] + st[row] * DIAG[row]
+    for (int i = 0; i < 12; i++) st[i] = F::pow7_out(st[i]);  // consumed by the SmallDot rows below only
+    if (!layer) return;
     T nx[12];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int row = 0; row < 12; row++) {
       typename F::SmallDot acc;
-      acc.add(st[row], POSEIDON_MDS_CIRC[0] + (row == 0 ? POSEIDON_MDS_DIAG0 : 0));
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-      for (int i = 1; i < 12; i++) acc.add(st[(i + row) % 12], POSEIDON_MDS_CIRC[i]);
+      for (int i = 0; i < 12; i++) acc.add(st[i], POSEIDON_FUSED.m[row][i]);
       nx[row] = acc.value_out();  // the next round adds a constant to it / subtracts a wire from it (first operands), or raises it
     }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int i = 0; i < 12; i++) st[i] = nx[i];
-  }
-  for (int i = 0; i < 12; i++) out.emit(F::sub(st[i], W(12 + i)));
+  };
+  // the S-box of partial round r on word 0: the wire holds its input
+  auto partial_sbox = [&](int r, T x0) {
+    const T sb = W(65 + (r - 4));
+    out.emit(F::sub(F::add(x0, F::from(prc[12 * r])), sb));
+    return F::pow7_out(sb);
+  };
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int r = 0; r < 3; r++) full_round(r, true);
+  full_round(3, false);
+  // linear layers r0, r0 + 1, r0 + 2 with the partial S-boxes of rounds r0 + 1, r0 + 2 between them, then round r0 + 3's
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int r0 = 3; r0 < 24; r0 += 3) {
+    typename F::SmallDot u1, u2;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 12; i++) u1.add(st[i], POSEIDON_FUSED.m[0][i]);
+    const T s1 = partial_sbox(r0 + 1, u1.value_out());
+    u2.add(s1, POSEIDON_FUSED.m[0][0]);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 12; i++) u2.add(st[i], POSEIDON_FUSED.mpm[0][i]);
+    const T s2 = partial_sbox(r0 + 2, u2.value_out());
+    T nx[12];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int row = 0; row < 12; row++) {
+      typename F::SmallDot acc;
+      acc.add(s1, POSEIDON_FUSED.mpm[row][0]);
+      acc.add(s2, POSEIDON_FUSED.m[row][0]);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int i = 0; i < 12; i++) acc.add(st[i], POSEIDON_FUSED.mpmpm[row][i]);
+      nx[row] = acc.value_out();
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 1; i < 12; i++) st[i] = nx[i];
+    st[0] = partial_sbox(r0 + 3, nx[0]);
+  }
+  {  // layers 24 and 25, round 25's S-box between them
+    typename F::SmallDot u1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 12; i++) u1.add(st[i], POSEIDON_FUSED.m[0][i]);
+    const T s1 = partial_sbox(25, u1.value_out());
+    T nx[12];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int row = 0; row < 12; row++) {
+      typename F::SmallDot acc;
+      acc.add(s1, POSEIDON_FUSED.m[row][0]);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int i = 0; i < 12; i++) acc.add(st[i], POSEIDON_FUSED.mpm[row][i]);
+      nx[row] = acc.value_out();
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 12; i++) st[i] = nx[i];
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int r = 26; r < 30; r++) full_round(r, true);
+  for (int i = 0; i < 12; i++) out.emit(F::sub(st[i], W(12 + i)));
+}
 
 // W(c): wire column c of this row; LC(i): local constant i; pih: public_inputs_hash;
-// prc: the 360 Poseidon round constants (only read when POSEIDON); out.emit(c) consumes
+// prc: the 360 Poseidon round constants, poseidon_device_constants form (only read when POSEIDON); out.emit(c) consumes
 // the constraints in order.
 template <class F, bool POSEIDON, class WF, class CF, class OUT>
 P2_HD void eval_gate(const GateDesc &g, WF W, CF LC, const typename F::T *pih, const gl_t *prc, OUT &out) {

@@ -214,6 +214,7 @@ int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off
     memcpy(c->circuit_digest.w, &h[32], c->hasher ? 32 : 25);
   }
   poseidon_round_constants_host(c->poseidon_rc);
+  poseidon_device_constants(c->poseidon_rc, c->poseidon_rc_gate);
   use_hasher(c);
   *off_out = off;
   return P2GPU_OK;

@@ -18,24 +18,8 @@
 namespace p2 {
 
 // ---- PoseidonHash (hasher 1): Poseidon-Goldilocks, width 12, 8 full + 22 partial rounds, x^7 -----------------
-// plonky2 0.2.2 hash/poseidon.rs in its plain form (constants added, S-box, MDS per round); the round
-// constants come from the handle's table in global memory (360 words, L1/L2 resident).  One lane owns one
-// sponge, like the Keccak path; rounds are not unrolled (the 12-word state, its MDS temporaries and the S-box
-// products already need ~70 VGPRs).
-__device__ __forceinline__ void poseidon_permute_dev(gl_t st[12], const gl_t *__restrict__ prc) {
-#pragma unroll 1
-  for (int r = 0; r < 30; r++) {
-    if (r < 4 || r >= 26) {
-#pragma unroll
-      for (int i = 0; i < 12; i++) st[i] = poseidon_sbox_nc(gl_add(st[i], prc[12 * r + i]));
-    } else {  // (prc = poseidon_device_constants: words 1..11 of a partial round have nothing to add)
-      st[0] = poseidon_sbox_nc(gl_add(st[0], prc[12 * r]));
-    }
-    poseidon_mds_dev(st);
-  }
-#pragma unroll
-  for (int i = 0; i < 12; i++) st[i] = gl_canon(st[i]);
-}
+// plonky2 0.2.2 hash/poseidon.rs; the permutation is poseidon.hpp's poseidon_permute_dev (one lane owns one sponge, like
+// the Keccak path; the partial rounds' linear layers three at a time).
 // hash_n_to_m_no_pad: overwrite-mode sponge, 8 elements per permutation, first 4 words out
 template <class F>
 __device__ __forceinline__ dig_t poseidon_sponge(uint32_t nwords, F get, const gl_t *prc) {

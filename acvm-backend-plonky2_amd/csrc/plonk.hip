@@ -29,7 +29,9 @@ __constant__ gl_t c_poseidon_rc[360];
 int poseidon_upload_constants() {
   gl_t rc[360];
   poseidon_round_constants_host(rc);
-  return hipMemcpyToSymbol(HIP_SYMBOL(c_poseidon_rc), rc, sizeof rc) == hipSuccess ? 0 : -1;
+  gl_t dev[360];  // the gate evaluator takes the form in which a partial round has a constant for word 0 only (gates.hpp)
+  poseidon_device_constants(rc, dev);
+  return hipMemcpyToSymbol(HIP_SYMBOL(c_poseidon_rc), dev, sizeof dev) == hipSuccess ? 0 : -1;
 }
 
 // ------------------------------------------------------------------------------

@@ -113,6 +113,155 @@ P2_HD uint64_t poseidon_sbox_nc(gl_t x) {
   return gl_mul_nc(x4, x3);
 }
 
+// ---- the partial rounds, three linear layers at a time --------------------------------------------------------------
+// plonky2 speeds the 22 partial rounds up by factoring the MDS matrix into sparse layers with FULL-SIZE coefficients (22
+// general products per round instead of 144 small ones) -- a good trade on a CPU, a bad one here: a product by an MDS entry
+// (< 2^6) is TWO v_mad_u64_u32 on the 32-bit halves of a word with the sum riding along in the addend, a general product
+// with its reduction is 18 VALU (profiles/r06_poseidon.md has the count).  What costs on gfx950 is the REDUCTION of the
+// twelve row sums after every layer.  In a partial round only word 0 meets the S-box, so words 1..11 pass from one
+// linear layer straight into the next, and small-integer matrices multiply into small-integer matrices: with
+// P = diag(0, 1, ..., 1) (drop word 0, it is replaced by the S-box output s)
+//     V' = P (M V) + s1 e0,   V'' = P (M V') + s2 e0,   W = M V''
+//     u1 = (M V)[0]                              -> s1 = sbox(u1 + c)
+//     u2 = (M P M V)[0] + s1 M[0][0]             -> s2 = sbox(u2 + c')
+//     W  = (M P M P M) V + s1 (M P M e0) + s2 (M e0)
+// M P M P M has entries < 2^23 and row sums < 2^24.2: the two 64-bit sums per row still cannot overflow (2^24.2 * 2^32 +
+// the s terms < 2^57).  Three layers cost 14 reductions and 386 multiply-adds instead of 36 and 864; the S-box inputs
+// u + c are the ones the plain form feeds, so the PoseidonGate's constraints (gates.hpp) take the same route.
+// The 23 linear layers from round 3 (after its S-boxes) to round 25 are 7 such triples and one pair.
+struct PoseidonFusedTables {
+  uint32_t m[12][12];      // M = circ(POSEIDON_MDS_CIRC) + diag(8, 0, ...)
+  uint32_t mpm[12][12];    // M P M
+  uint32_t mpmpm[12][12];  // M P M P M
+};
+constexpr PoseidonFusedTables poseidon_fused_tables() {
+  PoseidonFusedTables t{};
+  for (int r = 0; r < 12; r++)
+    for (int c = 0; c < 12; c++) t.m[r][c] = POSEIDON_MDS_CIRC[(c - r + 12) % 12] + ((r == 0 && c == 0) ? POSEIDON_MDS_DIAG0 : 0);
+  for (int r = 0; r < 12; r++)
+    for (int c = 0; c < 12; c++) {
+      uint64_t a = 0;
+      for (int k = 1; k < 12; k++) a += (uint64_t)t.m[r][k] * t.m[k][c];
+      t.mpm[r][c] = (uint32_t)a;
+    }
+  for (int r = 0; r < 12; r++)
+    for (int c = 0; c < 12; c++) {
+      uint64_t a = 0;
+      for (int k = 1; k < 12; k++) a += (uint64_t)t.m[r][k] * t.mpm[k][c];
+      t.mpmpm[r][c] = (uint32_t)a;
+    }
+  return t;
+}
+inline constexpr PoseidonFusedTables POSEIDON_FUSED = poseidon_fused_tables();
+constexpr bool poseidon_fused_fits() {  // every row of M P M P M (+ the two S-box columns) sums below 2^25: sums of 32-bit halves stay below 2^57
+  for (int r = 0; r < 12; r++) {
+    uint64_t s = POSEIDON_FUSED.mpm[r][0] + POSEIDON_FUSED.m[r][0];
+    for (int c = 0; c < 12; c++) s += POSEIDON_FUSED.mpmpm[r][c];
+    if (s >= (1ull << 25)) return false;
+  }
+  return true;
+}
+static_assert(poseidon_fused_fits(), "fused Poseidon layers: a row sum would overflow the 64-bit half sums");
+
+#if defined(__HIPCC__)
+// APPS (3 or 2) linear layers and the APPS - 1 partial S-boxes between them; c1, c2: the word-0 constants of those rounds
+// (poseidon_device_constants form).  In: any u64 words; out: congruent u64 words (not canonical).
+template <int APPS>
+__device__ __forceinline__ void poseidon_fused_dev(gl_t st[12], gl_t c1, gl_t c2) {
+  static_assert(APPS == 2 || APPS == 3, "two or three layers");
+  uint32_t vl[12], vh[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    vl[i] = (uint32_t)st[i];
+    vh[i] = (uint32_t)(st[i] >> 32);
+  }
+  auto fin = [](uint64_t lo, uint64_t hi) {
+    const uint64_t l = lo + (hi << 32);
+    return gl_reduce128_nc(l, (hi >> 32) + (l < lo));
+  };
+  uint64_t lo = 0, hi = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    lo += (uint64_t)vl[i] * POSEIDON_FUSED.m[0][i];
+    hi += (uint64_t)vh[i] * POSEIDON_FUSED.m[0][i];
+  }
+  const uint64_t s1 = poseidon_sbox_nc(gl_add(fin(lo, hi), c1));
+  const uint32_t s1l = (uint32_t)s1, s1h = (uint32_t)(s1 >> 32);
+  uint64_t s2 = 0;
+  if constexpr (APPS == 3) {
+    lo = (uint64_t)s1l * POSEIDON_FUSED.m[0][0];
+    hi = (uint64_t)s1h * POSEIDON_FUSED.m[0][0];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      lo += (uint64_t)vl[i] * POSEIDON_FUSED.mpm[0][i];
+      hi += (uint64_t)vh[i] * POSEIDON_FUSED.mpm[0][i];
+    }
+    s2 = poseidon_sbox_nc(gl_add(fin(lo, hi), c2));
+  }
+  const uint32_t s2l = (uint32_t)s2, s2h = (uint32_t)(s2 >> 32);
+#pragma unroll
+  for (int row = 0; row < 12; row++) {
+    if constexpr (APPS == 3) {
+      lo = (uint64_t)s1l * POSEIDON_FUSED.mpm[row][0] + (uint64_t)s2l * POSEIDON_FUSED.m[row][0];
+      hi = (uint64_t)s1h * POSEIDON_FUSED.mpm[row][0] + (uint64_t)s2h * POSEIDON_FUSED.m[row][0];
+    } else {
+      lo = (uint64_t)s1l * POSEIDON_FUSED.m[row][0];
+      hi = (uint64_t)s1h * POSEIDON_FUSED.m[row][0];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      const uint32_t k = APPS == 3 ? POSEIDON_FUSED.mpmpm[row][i] : POSEIDON_FUSED.mpm[row][i];
+      lo += (uint64_t)vl[i] * k;
+      hi += (uint64_t)vh[i] * k;
+    }
+    st[row] = fin(lo, hi);
+  }
+}
+// The whole permutation, one lane per state (hash/poseidon.rs permute).  prc = the handle's table in the
+// poseidon_device_constants form (words 1..11 of a partial round have nothing to add), global memory, L1/L2 resident.
+// Rounds are not unrolled (the 12-word state, the row sums and the S-box products already need ~70 VGPRs).
+#ifndef P2_POSEIDON_FUSED
+#define P2_POSEIDON_FUSED 1  // 0: every round through its own 12 x 12 layer (rounds 1-5; A/B measurements)
+#endif
+__device__ __forceinline__ void poseidon_permute_dev(gl_t st[12], const gl_t *__restrict__ prc) {
+#if P2_POSEIDON_FUSED
+#pragma unroll 1
+  for (int r = 0; r < 3; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = poseidon_sbox_nc(gl_add(st[i], prc[12 * r + i]));
+    poseidon_mds_dev(st);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) st[i] = poseidon_sbox_nc(gl_add(st[i], prc[36 + i]));
+#pragma unroll 1
+  for (int r0 = 3; r0 < 24; r0 += 3) {  // layers r0, r0 + 1, r0 + 2 and the partial S-boxes of rounds r0 + 1, r0 + 2; then round r0 + 3's
+    poseidon_fused_dev<3>(st, prc[12 * (r0 + 1)], prc[12 * (r0 + 2)]);
+    st[0] = poseidon_sbox_nc(gl_add(st[0], prc[12 * (r0 + 3)]));
+  }
+  poseidon_fused_dev<2>(st, prc[12 * 25], 0);  // layers 24, 25 and round 25's S-box
+#pragma unroll 1
+  for (int r = 26; r < 30; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = poseidon_sbox_nc(gl_add(st[i], prc[12 * r + i]));
+    poseidon_mds_dev(st);
+  }
+#else
+#pragma unroll 1
+  for (int r = 0; r < 30; r++) {
+    if (r < 4 || r >= 26) {
+#pragma unroll
+      for (int i = 0; i < 12; i++) st[i] = poseidon_sbox_nc(gl_add(st[i], prc[12 * r + i]));
+    } else {
+      st[0] = poseidon_sbox_nc(gl_add(st[0], prc[12 * r]));
+    }
+    poseidon_mds_dev(st);
+  }
+#endif
+#pragma unroll
+  for (int i = 0; i < 12; i++) st[i] = gl_canon(st[i]);
+}
+#endif
+
 #if defined(__HIPCC__)
 // ---- ONE Poseidon permutation spread over 12 lanes of a 16-lane group (four permutations per wave) --------------------
 // For the latency-bound tops of Poseidon Merkle trees: one lane per node is 25 000 dependent-issue instructions per level (a lone

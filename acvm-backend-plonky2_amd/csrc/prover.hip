@@ -2182,6 +2182,9 @@ static int prove_host(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, c
     ~Joiner() { if (t.joinable()) t.join(); }
   } joiner{scan_thread};
   if (int rc = make_tail()) return rc;
+  // (Round 6 tried ONE bulk upload + the resident path whenever other proofs are in flight on the device -- their kernels fill
+  // the chip anyway: 192 proofs/s against 205 with the chunks, same box, four in flight, pageable witness: the staging copy of
+  // 84 MB then sits on the calling thread in one piece in front of the proof instead of under its own transforms.  Removed.)
   // The witness crosses PCIe in column chunks on a copy stream; the inverse transform and the
   // LDE of a chunk run while the next chunk is still in flight (values -> coefficients -> LDE are
   // per-column; only the leaf hash needs every column).

@@ -71,7 +71,7 @@ bool plonk_identity_holds(const p2gpu_circuit *c, const std::vector<ext_t> &op, 
     const ext_t f = gate_filter<ExtOps>(g, gi, c->num_selectors, o_const[g.sel_index]);
     cons.clear();
     CollectOut out{&cons};
-    eval_gate<ExtOps, true>(g, Wf, LC, pih_e, c->poseidon_rc, out);
+    eval_gate<ExtOps, true>(g, Wf, LC, pih_e, c->poseidon_rc_gate, out);
     for (size_t k = 0; k < cons.size() && k < gate_terms.size(); k++)
       gate_terms[k] = ext_add(gate_terms[k], ext_mul(f, cons[k]));
   }

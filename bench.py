@@ -253,7 +253,8 @@ def compact_line(out, detail_name="bench_detail.json"):
     for k in ("latency_ms_single_proof", "latency_ms_single_proof_host_witness", "value_host_witness", "cold_process_ms"):
         line[k] = out.get(k)
     if (out.get("n_gpus") or 1) > 1 or out.get("peer_access") is not None:
-        for k in ("latency_ms_sharded", "latency_ms_sharded_group", "rccl_ranks", "peer_access", "ranks_share_devices"):
+        for k in ("latency_ms_sharded", "latency_ms_sharded_intt", "latency_ms_sharded_group", "latency_ms_sharded_group_intt", "rccl_ranks", "peer_access",
+                  "ranks_share_devices"):
             line[k] = out.get(k)
         sh = out.get("sharded") or {}
         if sh.get("error"):
@@ -445,12 +446,22 @@ def group_probe(pkg, args, group, blob, wires, pis):
     for _ in range(k):
         cd.prove(wd, public_inputs=pis)
     ms = (time.perf_counter() - t0) / k * 1e3
+    # knob shard_intt: column-sharded inverse transforms + all-gather of the coefficient blocks (peer copies, in place)
+    cd.set("shard_intt", 1)
+    same = cd.prove(wd, public_inputs=pis).to_bytes() == ref.to_bytes()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        cd.prove(wd, public_inputs=pis)
+    ms_intt = (time.perf_counter() - t0) / k * 1e3
+    cd.set("shard_intt", 0)
     cd.set("profile", 2)
     for _ in range(2):
         cd.prove(wd, public_inputs=pis)
     st = cd.kernel_stats()
     cd.set("profile", 0)
-    out = {"devices": group, "latency_ms_sharded_group": ms, "proofs": k, "peer_access": pkg.peer_access(),
+    out = {"devices": group, "latency_ms_sharded_group": ms, "latency_ms_sharded_group_intt": ms_intt, "shard_intt_same_bytes": same,
+           "proofs": k, "peer_access": pkg.peer_access(),
            "exchanges": exchange_stats(st, 2), "proof_bytes": len(ref),
            "transport": "hipMemcpyPeerAsync between the ranks' streams, one host thread per rank inside p2gpu_prove_dev"}
     cd.close()
@@ -683,8 +694,16 @@ def main():
         assert group, "--group-probe needs --group"
         print(json.dumps(group_probe(pkg, args, group, blob, wires, pis)), flush=True)
         return
-    S = 1 if sharded else max(1, min(args.in_flight, args.steps, 1 if d >= 21 else (2 if d == 20 else 8)))
-    cds = [pkg.CircuitData(blob) for _ in range(S)]
+    # proofs in flight = handles: as many as asked for, as long as HBM holds them (a handle allocates everything at create:
+    # 0.4 GB at 2^20 rows, ~55 GB at 2^24 -- 288 GB take four of those; rounds 1-5 ran 2^24 rows one proof at a time)
+    S_want = 1 if sharded else max(1, min(args.in_flight, args.steps, 8))
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    cds = [pkg.CircuitData(blob)]
+    handle_bytes = max(1, free0 - torch.cuda.mem_get_info()[0])
+    while len(cds) < S_want and torch.cuda.mem_get_info()[0] > 1.1 * handle_bytes + wires.nbytes + (4 << 30):
+        cds.append(pkg.CircuitData(blob))
+    S = len(cds)
     blocking = (world * S * 2 > effective_cores()) if args.blocking_sync == "auto" else args.blocking_sync == "1"
     if blocking:
         for cd_ in cds:
@@ -941,13 +960,32 @@ def main():
                 pr1 = csh.prove(w1, public_inputs=pis1)
             barrier()
             sh_ms = pkg.parallel.max_over_ranks(time.perf_counter() - t1) / args.sharded_steps * 1e3
+            # the same proof with the inverse transforms of the wires / Z-PP column-sharded and the coefficient blocks all-gathered
+            # (knob shard_intt) instead of replicated: same bytes, the first multi-GPU lease decides the default
+            csh.set("shard_intt", 1)
+            pr2 = csh.prove(w1, public_inputs=pis1)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.sharded_steps):
+                pr2 = csh.prove(w1, public_inputs=pis1)
+            barrier()
+            sh_ms_intt = pkg.parallel.max_over_ranks(time.perf_counter() - t1) / args.sharded_steps * 1e3
+            intt_same = pr2.to_bytes() == pr1.to_bytes()
+            csh.set("profile", 2)
+            for _ in range(2):
+                csh.prove(w1, public_inputs=pis1)
+            xst_intt = exchange_stats(csh.kernel_stats(), 2)
+            csh.set("profile", 0)
+            csh.set("shard_intt", 0)
             csh.set("profile", 2)
             for _ in range(2):
                 csh.prove(w1, public_inputs=pis1)
             xst = exchange_stats(csh.kernel_stats(), 2)
             csh.set("profile", 0)
             barrier()
-            sharded_half_ = {"latency_ms_sharded": sh_ms, "proofs": args.sharded_steps, "rccl_ranks": world if args.backend == "nccl" else 0,
+            sharded_half_ = {"latency_ms_sharded": sh_ms, "latency_ms_sharded_intt": sh_ms_intt, "shard_intt_same_bytes": intt_same,
+                            "exchanges_rank0_shard_intt": xst_intt,
+                            "proofs": args.sharded_steps, "rccl_ranks": world if args.backend == "nccl" else 0,
                             "transport": ("RCCL called by the library on each rank's stream (grouped ncclSend/ncclRecv >= 1 MB, ncclAllGather below)"
                                           if args.backend == "nccl" else f"host callback over torch.distributed/{args.backend} (functional check, ranks may share a GPU)"),
                             "exchanges_rank0": xst, "proof_bytes": len(pr1),
@@ -1123,6 +1161,8 @@ def main():
             "latency_ms_single_proof": single_ms,
             "latency_ms_sharded": sharded_half["latency_ms_sharded"] if sharded_half else None,
             "latency_ms_sharded_group": (sharded_half.get("group") or {}).get("latency_ms_sharded_group") if sharded_half else None,
+            "latency_ms_sharded_intt": sharded_half.get("latency_ms_sharded_intt") if sharded_half else None,
+            "latency_ms_sharded_group_intt": (sharded_half.get("group") or {}).get("latency_ms_sharded_group_intt") if sharded_half else None,
             "rccl_ranks": sharded_half["rccl_ranks"] if sharded_half else (world if sharded and args.backend == "nccl" else 0),
             "peer_access": (sharded_half.get("group") or {}).get("peer_access") if sharded_half else (pkg.peer_access() if group else None),
             "sharded": sharded_half,
@@ -1135,6 +1175,7 @@ def main():
             "single_proof": {"in_flight": 1, "ms_per_proof": single_ms, "proofs_per_sec": (1 if sharded else world) * 1e3 / single_ms,
                              "note": "one proof on the GPU at a time (the round-1 headline configuration)"},
             "in_flight_per_gpu": S,
+            "resident_bytes_per_handle": handle_bytes,
             "blocking_sync": bool(blocking),
             "host_witness": host,
             "pipelined": pipe,

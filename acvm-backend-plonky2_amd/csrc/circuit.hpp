@@ -206,6 +206,13 @@ struct CircuitState {
   std::vector<gl_t> k_is;
   uint32_t nterms = 0, max_gate_constraints = 0;
   uint32_t gate_groups = 1;  // quotient kernel: 1, or 4 when the gate set is heavy
+  // gates of degree <= 4 evaluated on the even cosets only, their folded sums extended to the odd cosets (plonk.hip gate_sums_kernel)
+  uint32_t half_slots = 0;        // number of such gates (0: none worth it)
+  uint32_t gate_groups_half = 1;  // waves per row tile of the main kernel when those gates are looked up
+  uint32_t sums_groups = 1;       // ... of gate_sums_kernel
+  int half_gates = 1;             // knob "half_gates"
+  gl_t half_cross[16];            // the even -> odd cross-coset matrix (gate_sums_cross_kernel)
+  DBuf<gl_t> hsum, htmp_a, htmp_b;
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // H2D of the witness, overlapped with the transforms of earlier columns
@@ -308,6 +315,7 @@ int circuit_parse(const uint8_t *blob, size_t len, p2gpu_circuit *c, size_t *off
 const char *gate_validate(uint32_t kind, const uint32_t p[4], uint32_t W, uint32_t gate_consts, uint64_t *wires_used,
                           uint32_t *consts_used);
 uint32_t gate_num_constraints(uint32_t kind, const uint32_t p[4]);
+uint32_t gate_degree(uint32_t kind, const uint32_t p[4]);
 // the verifier's plonk identity at zeta on the opened values (verify.hip); also the prover's self-check
 bool plonk_identity_holds(const p2gpu_circuit *c, const std::vector<ext_t> &op, const gl_t *betas, const gl_t *gammas,
                           const gl_t *alphas, ext_t zeta, const gl_t pih[4]);

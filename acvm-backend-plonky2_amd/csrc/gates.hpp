@@ -29,6 +29,16 @@ struct GateDesc {
   uint32_t num_constraints, degree, num_constants, pad;  // pad: evaluation group (quotient kernel, heavy mixes)
 };
 
+// GateDesc.pad, set at circuit create (prover.hip): which wave of a four-wave block evaluates the gate, and whether its folded
+// constraint sum comes from the half-domain evaluation (plonk.hip gate_sums_kernel)
+//   bits 0-3   group when every gate is evaluated directly on every row
+//   bits 4-7   group in the main kernel when the half-domain gates are looked up there
+//   bits 8-11  group in gate_sums_kernel
+//   bits 16-23 half-domain slot + 1 (0: evaluated directly)
+P2_HD uint32_t gate_group(const GateDesc &g, uint32_t use_half) { return use_half ? (g.pad >> 4) & 15u : g.pad & 15u; }
+P2_HD uint32_t gate_sums_group(const GateDesc &g) { return (g.pad >> 8) & 15u; }
+P2_HD uint32_t gate_half_slot(const GateDesc &g) { return (g.pad >> 16) & 255u; }
+
 struct BaseOps {
   typedef gl_t T;
   static P2_HD T from(uint64_t x) { return x; }  // x < p

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Generator of keccak_sched.inc -- the device Keccak-f[1600] round pair as an explicitly ORDERED instruction stream.
+"""LIBRARY of gen_keccak_fixed.py (which imports the operation list and the list scheduler from here and emits keccak_fixed.inc,
+the file keccak.hpp includes).  Its own output, keccak_sched.inc -- the device Keccak-f[1600] round pair as an explicitly ORDERED
+instruction stream on compiler-allocated registers -- was the round-3 form; the file left the tree in round 5.
 
 Why (profiles/r03_ubench.txt, scratch/ubench/gen_issue.py + gen_bank.py, MI355X): a gfx950 SIMD retires a wave64
 v_bitop3_b32 in 2.2 cycles but a v_alignbit_b32 (every rotate of Keccak) in 4.15, and a stream that alternates
@@ -11,7 +13,7 @@ the B,B,A pattern: row by row, theta of the five lanes that feed a row of B, the
 the column parities of the NEXT round accumulated as the rows come out.
 
 The operation list is checked in this script against a plain Python Keccak-f (python gen_keccak_sched.py --check).
-Output: keccak_sched.inc, included by keccak.hpp for device code only.  Regenerate: python gen_keccak_sched.py > keccak_sched.inc
+Stand-alone use today: `python gen_keccak_sched.py --check` (the self-check); the printed stream is no longer included anywhere.
 """
 import sys
 

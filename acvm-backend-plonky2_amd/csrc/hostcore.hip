@@ -117,6 +117,24 @@ const char *gate_validate(uint32_t kind, const uint32_t p[4], uint32_t W, uint32
   return nullptr;
 }
 
+// degree of the gate's constraints as polynomials in the wire / constant columns (the library's own count from the formulas
+// of gates.hpp, not the blob's `degree` field): what the half-domain evaluation of plonk.hip gate_sums_kernel relies on
+uint32_t gate_degree(uint32_t kind, const uint32_t p[4]) {
+  switch (kind) {
+  case G_NOOP: return 0;
+  case G_CONSTANT: case G_PUBLIC_INPUT: return 1;
+  case G_ARITHMETIC: return 3;
+  case G_BASE_SUM: return p[0] > 1 ? p[0] : 1;
+  case G_RANDOM_ACCESS: return p[0] + 1;
+  case G_POSEIDON: return 7;
+  case G_U32_ARITHMETIC: case G_U32_ADD_MANY: case G_U32_SUBTRACTION: case G_U32_RANGE_CHECK: return 4;  // range4 of a 2-bit limb
+  case G_COMPARISON: {
+    const uint32_t cb = p[1] ? (p[0] + p[1] - 1) / p[1] : 32;
+    return cb >= 31 ? UINT32_MAX : std::max(1u << cb, 3u);
+  }
+  default: return UINT32_MAX;
+  }
+}
 uint32_t gate_num_constraints(uint32_t kind, const uint32_t p[4]) {
   switch (kind) {
   case G_NOOP: return 0;

@@ -71,7 +71,10 @@ struct ColHints {
   const gl_t *basis = nullptr;      // this transform of the unit column: [n], or [all cosets][n] (indexed by GLOBAL coset);
                                     // special row s at basis + s * basis_stride
   bool basis_per_coset = false;
-  uint32_t nrows = 1, val_stride = 0;
+  uint32_t nrows = 1, val_stride = 0;  // INVARIANT the launchers rely on (ntt_batch's fill grid, the profile's byte counts): class 3
+                                       // exists only when nrows > 1 (column_class_kernel: with one special row a column that is zero
+                                       // elsewhere is class 1) -- a classifier that hands out class 3 with nrows == 1 must also
+                                       // widen the fill grid beyond virt_first
   size_t basis_stride = 0;
   uint32_t virt_first = UINT32_MAX; // columns >= virt_first (relative to cls) of class 0 / 1 are not stored at all: their
                                     // consumers recompute val[c] * basis on the fly (VirtCols)
@@ -156,7 +159,11 @@ struct QuotArgs {
   const GateDesc *host_gates;  // the same table on the host (launch-time decisions)
   gl_t *out;             // [K][cosets][n]
   uint32_t tw_shift, d, rate_bits, W, R, NC, num_selectors, K, QF, nchunks, PP, num_gates, nterms, has_poseidon;
-  uint32_t gate_groups;  // 1, or 4: gates split over the four waves of a 64-row block (GateDesc.pad = group)
+  uint32_t gate_groups;  // 1, or 4: gates split over the four waves of a 64-row block (GateDesc.pad: gates.hpp gate_group)
+  uint32_t gate_groups_half;  // the same for the main kernel when the half-domain gates are only looked up (use_half)
+  uint32_t use_half;     // gates of degree <= 4 with a slot: sums from hsum instead of evaluating them (plonk.hip gate_sums_kernel)
+  uint32_t nsk;          // half-domain slots x K
+  gl_t *hsum;            // [2][4][nsk][n]: folded sums on the even cosets (parity 0) and the odd ones (parity 1)
   uint32_t coset_first, coset_stride, ncosets;  // sharding: grid.y = local coset z, global r = first + z * stride;
                                                 // cs_lde/qconst are indexed by r, wires/zp/out by z
   gl_t betas[MAX_CHALLENGES], gammas[MAX_CHALLENGES];
@@ -167,6 +174,10 @@ struct QuotArgs {
   const gl_t *l0;       // [all cosets][n] (global coset index): L_0(x) = Z_H(x) / (n (x - 1)), fill_l0_table
 };
 void quotient_eval(hipStream_t st, const QuotArgs &a);
+// folded constraint sums of the half-domain gates on the even cosets -> a.hsum parity 0 (groups: 1 or 4 waves per row tile)
+void gate_sums_eval(hipStream_t st, const QuotArgs &a, uint32_t groups);
+// in / out [4][cols][n]: per-coset interpolants of the even cosets -> coefficient arrays of the odd cosets (F: HalfGates::cross)
+void gate_sums_cross(hipStream_t st, const gl_t *in, const gl_t *inv_scale, gl_t *out, uint32_t d, uint32_t cols, const gl_t F[16]);
 // out[r][k] = qconst[8 + r] * n_inv / (qconst[r] * w_n^k - 1): per circuit, so that the quotient kernel loads L_0
 // instead of inverting x - 1 on every row (~125 modmuls of the ~1 200 a row of the permutation argument costs)
 void fill_l0_table(hipStream_t st, const gl_t *qconst, const gl_t *tw, uint32_t tw_shift, uint32_t d, uint32_t cosets, gl_t n_inv, gl_t *out);

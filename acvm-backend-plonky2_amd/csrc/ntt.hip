@@ -1025,6 +1025,10 @@ NttPlan *ntt_plan_create(hipStream_t st, uint32_t d, int dit, bool inverse) {
     p->passes.push_back(np);
   }
   p->table_len = total;
+  if (total >> 32) {  // tw_off / ftw_off / ftw2_off are 32-bit word offsets (d = 24 with its folded tables: ~2^25 words)
+    delete p;
+    return nullptr;
+  }
   if (total) {
     if (hipMalloc((void **)&p->ptw, total * sizeof(gl_t)) != hipSuccess) {
       delete p;

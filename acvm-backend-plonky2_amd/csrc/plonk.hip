@@ -269,9 +269,16 @@ __global__ __launch_bounds__(256, P2_QUOT_WAVES) void quotient_kernel(const Quot
     const GateDesc g = a.gates[gi];
     if (g.num_constraints == 0) continue;
     if (!POSEIDON && g.kind == G_POSEIDON) continue;  // evaluated by poseidon_gate_kernel
-    if (G > 1 && g.pad != grp) continue;
+    if (G > 1 && gate_group(g, a.use_half) != grp) continue;
     const gl_t s = cs[(size_t)g.sel_index * n];
     const gl_t f = gate_filter<BaseOps>(g, gi, a.num_selectors, s);
+    if (const uint32_t slot1 = a.use_half ? gate_half_slot(g) : 0u) {
+      // a gate of degree <= 4: its alpha-folded sum was evaluated on the even cosets and extended to the odd ones (gate_sums)
+      const gl_t *h = a.hsum + ((size_t)((r & 1u) * 4u + (r >> 1)) * a.nsk + (size_t)(slot1 - 1) * a.K) * n + k;
+      tot0 = gl_mul_add(f, h[0], tot0);
+      if (a.K > 1) tot1 = gl_mul_add(f, h[n], tot1);
+      continue;
+    }
     out.acc0.clear();
     out.acc1.clear();
     out.t = t_gates;
@@ -292,6 +299,84 @@ __global__ __launch_bounds__(256, P2_QUOT_WAVES) void quotient_kernel(const Quot
   const gl_t zi = a.qconst[16 + r];
   a.out[((size_t)0 * a.ncosets + z) * n + k] = gl_mul(tot0, zi);
   if (a.K > 1) a.out[((size_t)1 * a.ncosets + z) * n + k] = gl_mul(tot1, zi);
+}
+
+// ---- gates of degree <= 4 on HALF the LDE domain -----------------------------------------------------------------------------
+// The alpha-folded constraint sum of a gate, S_g(x) = sum_t alpha^t c_t(x), is a polynomial of degree < deg(g) * n before the
+// selector filter multiplies it.  The reference's five custom gates, BaseSum<4> and everything else built on 2-bit limb range
+// checks have degree 4 (arithmetic_u32.rs:44 `1 << Self::limb_bits()`, comparison.rs `1 << self.chunk_bits()`): S_g is fixed by
+// its values on ANY 4n points -- the four even cosets r = 0, 2, 4, 6 are the coset g <w_4n> -- and the values on the odd cosets
+// follow by interpolation: four size-n inverse transforms, a 4 x 4 cross-coset matrix, four size-n transforms, per
+// (gate, challenge) instead of ~200 constraints x 77 VALU on every row of four more cosets.  Exact field arithmetic: the same
+// words the direct evaluation gives (tests: proofs bit-exact, knob "half_gates" 0 / 1).  synth(19, ecdsa): 855 of 940
+// constraints per row are such gates.
+// out: hsum [parity][m][slot * K + c][n] (coset r = 2 m + parity); this kernel writes parity 0.
+template <int G>
+__global__ __launch_bounds__(256, P2_QUOT_WAVES) void gate_sums_kernel(const QuotArgs a) {
+  const uint32_t grp = G > 1 ? threadIdx.y : 0;
+  const uint32_t n = 1u << a.d;
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t m = blockIdx.y, r = 2u * m;
+  if (k >= n) return;
+  const uint32_t ncs = a.NC + a.R;
+  const gl_t *cs = a.cs_lde + (size_t)r * ncs * n + k;
+  const gl_t *wl = a.wires_lde + (size_t)r * a.W * n + k;   // (only with every coset local: z = r)
+  Consumer out;
+  out.ap0 = a.apow;
+  out.ap1 = a.apow + a.nterms;
+  auto W = [&](uint32_t c) { return wl[(size_t)c * n]; };
+  auto LC = [&](uint32_t i) { return cs[(size_t)(a.num_selectors + i) * n]; };
+  for (uint32_t gi = 0; gi < a.num_gates; gi++) {
+    const GateDesc g = a.gates[gi];
+    const uint32_t slot1 = gate_half_slot(g);
+    if (!slot1) continue;
+    if (G > 1 && gate_sums_group(g) != grp) continue;
+    out.acc0.clear();
+    out.acc1.clear();
+    out.t = a.K + a.K * a.nchunks;
+    eval_gate<BaseOps, false>(g, W, LC, a.pi_hash, c_poseidon_rc, out);
+    gl_t *h = a.hsum + ((size_t)m * a.nsk + (size_t)(slot1 - 1) * a.K) * n + k;
+    h[0] = out.acc0.value();
+    if (a.K > 1) h[n] = out.acc1.value();
+  }
+}
+// even cosets -> odd cosets, between the per-coset inverse and forward transforms: in [m][col][n] = coefficients (bit-reversed
+// positions) of P_m(y) = S(s_2m y); with inv_scale[r][p] = s_r^-e (e = bitrev p) P'_m = sum_j w_8^(2 m j) A_j, A_j = (g^n)^j S_j[e]
+// (S = sum_j x^(j n) S_j), and the odd coset 2 m' + 1 wants sum_j w_8^((2 m' + 1) j) A_j: out[m'] = sum_m F[m'][m] P'_m,
+// F[m'][m] = 1/4 sum_j w_8^((2 m' + 1 - 2 m) j) (host: HalfGates::cross).  The forward transform applies s_(2m'+1)^e itself.
+struct CrossMat {
+  gl_t f[4][4];
+};
+__global__ __launch_bounds__(256) void gate_sums_cross_kernel(const gl_t *__restrict__ in, const gl_t *__restrict__ inv_scale, gl_t *__restrict__ out,
+                                                             uint32_t d, uint32_t cols, CrossMat F) {
+  const uint32_t n = 1u << d;
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+  if (p >= n) return;
+  gl_t P[4];
+#pragma unroll
+  for (uint32_t m = 0; m < 4; m++) P[m] = gl_mul(in[((size_t)m * cols + col) * n + p], inv_scale[(size_t)(2 * m) * n + p]);
+#pragma unroll
+  for (uint32_t mo = 0; mo < 4; mo++) {
+    Acc160 acc;
+    acc.clear();
+#pragma unroll
+    for (uint32_t m = 0; m < 4; m++) acc.mac(F.f[mo][m], P[m]);
+    out[((size_t)mo * cols + col) * n + p] = acc.value();
+  }
+}
+void gate_sums_eval(hipStream_t st, const QuotArgs &a, uint32_t groups) {
+  const uint32_t n = 1u << a.d;
+  const char *name = groups == 4 ? "gate_sums_kernel<4>" : "gate_sums_kernel<1>";
+  ProfScope ps(name, 8.0 * (double)n * 4 * (a.W + a.num_selectors + 1.0 * a.nsk));
+  if (groups == 4) hipLaunchKernelGGL((gate_sums_kernel<4>), dim3(n / 64, 4), dim3(64, 4), 0, st, a);
+  else hipLaunchKernelGGL((gate_sums_kernel<1>), dim3((n + 255) / 256, 4), dim3(256), 0, st, a);
+}
+void gate_sums_cross(hipStream_t st, const gl_t *in, const gl_t *inv_scale, gl_t *out, uint32_t d, uint32_t cols, const gl_t F[16]) {
+  const uint32_t n = 1u << d;
+  CrossMat M;
+  for (int i = 0; i < 16; i++) M.f[i / 4][i % 4] = F[i];
+  ProfScope ps("gate_sums_cross_kernel", 8.0 * (double)n * cols * 8);
+  hipLaunchKernelGGL(gate_sums_cross_kernel, dim3((n + 255) / 256, cols), dim3(256), 0, st, in, inv_scale, out, d, cols, M);
 }
 
 // The PoseidonGate term on its own grid (circuits with public inputs): 118 S-boxes and 30 MDS layers
@@ -342,7 +427,7 @@ void fill_l0_table(hipStream_t st, const gl_t *qconst, const gl_t *tw, uint32_t 
 void quotient_eval(hipStream_t st, const QuotArgs &a) {
   const uint32_t n = 1u << a.d;
   const uint32_t threads = n >= 256 ? 256 : 64;
-  const bool split = a.gate_groups == 4 && n >= 64;
+  const bool split = (a.use_half ? a.gate_groups_half : a.gate_groups) == 4 && n >= 64;
   // same spelling as rocprofv3's demangled names
   {
     const char *name = split ? "quotient_kernel<false, 4>" : "quotient_kernel<false, 1>";

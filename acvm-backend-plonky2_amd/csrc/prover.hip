@@ -829,6 +829,22 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     (void)wN;
     q.n_inv = gl_inv((gl_t)n);
     q.l0 = c->l0_lde.p;
+    // gates of degree <= 4: folded sums on the even cosets, extended to the odd ones (only with every coset on this device)
+    q.gate_groups_half = c->gate_groups_half;
+    q.nsk = c->half_slots * K;
+    q.hsum = c->hsum.p;
+    q.use_half = c->half_gates && c->half_slots && c->wires.ncl == C && c->wires.cm.stride == 1 && c->wires.cm.first == 0;
+    if (q.use_half) {
+      const size_t per = (size_t)4 * q.nsk * n;
+      gate_sums_eval(st, q, n >= 64 ? c->sums_groups : 1u);
+      ntt_batch(st, c->plan_inv, c->hsum.p, c->htmp_a.p, 4 * q.nsk, 1, nullptr, q.n_inv, false);
+      gate_sums_cross(st, c->htmp_a.p, c->inv_scale.p, c->htmp_b.p, d, q.nsk, c->half_cross);
+      CosetMap odd;
+      odd.first = 1;
+      odd.stride = 2;
+      ntt_batch(st, c->plan_fwd, c->htmp_b.p, c->hsum.p + per, q.nsk, 4, c->scale.p, 1, true, odd);
+      TRACE(c, "gate sums (half domain)");
+    }
     {
       quotient_eval(st, q);
     }
@@ -1269,6 +1285,7 @@ void circuit_release(p2gpu_circuit *c) {
   c->tw_fwd.release(); c->tw_inv.release(); c->scale.release(); c->inv_scale.release(); c->d_kis.release();
   c->d_sigmas.release(); c->fri_scale.release(); c->d_gates.release(); c->qconst.release(); c->l0_lde.release();
   c->d_row_gate.release(); c->d_gconsts.release(); c->d_prc.release(); c->d_prc_hash.release(); c->qconst.release();
+  c->hsum.release(); c->htmp_a.release(); c->htmp_b.release();
   c->cs.release(); c->wires.release(); c->zp.release(); c->quot.release();
   c->wires_vals.release(); c->zp_vals.release(); c->cp.release(); c->rowprod.release(); c->scan_tmp.release();
   c->apow.release(); c->qvals.release(); c->qtmp.release(); c->pw.release(); c->partial.release();
@@ -1619,6 +1636,40 @@ static int circuit_create_one(const uint8_t *blob, size_t len, int device, p2gpu
       c->gates[gi].pad = c->gate_groups == 4 ? best : 0;
       load[best] += cost(c->gates[gi]);
     }
+    // Gates of degree <= 4 with enough constraints to pay for two transforms per challenge: evaluated on the even cosets only
+    // (plonk.hip gate_sums_kernel).  The degree is the library's own count (gate_degree), not the blob's field.
+    const char *he = getenv("P2GPU_HALF_GATES");  // 0: off (A/B measurements); the knob "half_gates" does the same per handle
+    uint32_t half_cost = 0;
+    if (!(he && *he == '0') && c->d >= 10 && c->rate_bits == 3)
+      for (auto &g : c->gates)
+        if (g.kind != G_POSEIDON && g.num_constraints >= 48 && gate_degree(g.kind, g.p) <= 4 && c->half_slots < 64) {
+          g.pad |= (++c->half_slots) << 16;
+          half_cost += cost(g);
+        }
+    if (c->half_slots) {
+      // the main kernel without them: a look-up and two products per gate and challenge
+      auto cost_main = [&](const GateDesc &g) { return gate_half_slot(g) ? 8u : cost(g); };
+      uint32_t rest = 0;
+      for (auto &g : c->gates) rest += cost_main(g);
+      c->gate_groups_half = rest > 2 * perm_cost ? 4u : 1u;
+      uint32_t lm[4] = {perm_cost, 0, 0, 0}, ls[4] = {0, 0, 0, 0};
+      const char *sge = getenv("P2GPU_SUMS_GROUPS");  // balance experiments only
+      c->sums_groups = sge ? (atoi(sge) == 4 ? 4u : 1u) : (c->half_slots >= 2 ? 4u : 1u);
+      for (uint32_t gi : order) {
+        GateDesc &g = c->gates[gi];
+        uint32_t bm = 0, bs = 0;
+        for (uint32_t q = 1; q < 4; q++) {
+          if (lm[q] < lm[bm]) bm = q;
+          if (ls[q] < ls[bs]) bs = q;
+        }
+        if (c->gate_groups_half == 4) g.pad |= bm << 4;
+        lm[bm] += cost_main(g);
+        if (gate_half_slot(g)) {
+          if (c->sums_groups == 4) g.pad |= bs << 8;
+          ls[bs] += cost(g);
+        }
+      }
+    }
   }
   const size_t n = c->n;
   if (len < off + 8 * ((size_t)c->NC * n + (size_t)c->R * n)) return fail(P2GPU_E_BLOB, "blob truncated (tables)");
@@ -1673,6 +1724,24 @@ static int circuit_create_one(const uint8_t *blob, size_t len, int device, p2gpu
   fill_powers(st, c->tw_inv.p, gl_inv(wn), (uint32_t)half);
   fill_coset_scale(st, c->scale.p, GL_GEN, wN, d, C, 1);
   fill_coset_scale(st, c->inv_scale.p, gl_inv(GL_GEN), gl_inv(wN), d, C, 1);
+  if (c->half_slots) {
+    const size_t per = (size_t)4 * c->half_slots * K * n;
+    CK(c->hsum.alloc(2 * per), "alloc gate sums");
+    CK(c->htmp_a.alloc(per), "alloc gate sums");
+    CK(c->htmp_b.alloc(per), "alloc gate sums");
+    // F[m'][m] = 1/4 sum_j w_8^((2 m' + 1 - 2 m) j): even cosets' interpolants -> odd cosets' coefficient arrays
+    const gl_t w8 = gl_root(3), quarter = gl_inv(4);
+    for (int mo = 0; mo < 4; mo++)
+      for (int m = 0; m < 4; m++) {
+        const gl_t base = gl_pow(w8, (uint64_t)((2 * mo + 1 - 2 * m + 16) % 8));
+        gl_t acc = 0, pw = 1;
+        for (int j = 0; j < 4; j++) {
+          acc = gl_add(acc, pw);
+          pw = gl_mul(pw, base);
+        }
+        c->half_cross[4 * mo + m] = gl_mul(acc, quarter);
+      }
+  }
   CK(c->qconst.alloc(24), "alloc qconst");
   {
     // ZeroPolyOnCoset: Z_H on the LDE coset has period 2^rate_bits
@@ -1882,6 +1951,7 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
   else if (k == "self_check") c->self_check = (int)value;
   else if (k == "shard_exercise") c->shard_exercise = (int)value;
   else if (k == "shard_intt") c->shard_intt = (int)value;
+  else if (k == "half_gates") c->half_gates = (int)value;
   else if (k == "blocking_sync") c->blocking_sync = (int)value;
   else if (k == "virtual_columns") {
     c->virtual_columns = (int)value;

@@ -246,6 +246,8 @@ static void batch_commit(batch_t *b, unsigned cap_h) {
    * LDE (2 x 31 GB at 2^24 rows -- ADVICE r03, VERDICT r04 missing 2) */
   size_t CB = nc;
   {
+    /* ORC_COMMIT_BLOCK has TWO meanings: a value below 4096 is a COLUMN count per block (what the tests pass: 8),
+     * anything else is the staging buffer's size in BYTES (default 2 GB), from which the column count is derived */
     const char *e = getenv("ORC_COMMIT_BLOCK");
     const size_t cap = e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)1 << 31;   /* bytes of staging, default 2 GB */
     const size_t fit = (cap / (sizeof(gl_t) * N)) & ~(size_t)7;

@@ -1065,7 +1065,43 @@ def test_other_cap_heights_and_pow_bits(pkg, orc, gpu, d, mix, cap_h, pow_bits, 
     oc.close()
 
 
-@pytest.mark.parametrize("env", [{"P2GPU_HOST_PRESCAN": "0"}, {"P2GPU_NTT_DIRECT": "0", "P2GPU_LEAF_LEVELS": "0"}])
+@pytest.mark.parametrize("d,mix,npi,W", [(10, "ecdsa", 0, 234), (12, "ecdsa", 3, 234), (13, "grammar", 0, 234), (11, "ecdsa", 2, 135), (15, "ecdsa", 0, 234)])
+def test_half_domain_gates_keep_every_byte(pkg, orc, gpu, d, mix, npi, W):
+    """Round 6: the folded constraint sums of the gates of degree <= 4 (the reference's five custom gates, BaseSum<4>) are
+    evaluated on the four even LDE cosets only and extended to the odd ones by interpolation (plonk.hip gate_sums_kernel) --
+    a polynomial of degree < 4n is fixed by 4n values, so every quotient word, and with it every proof byte, is the one the
+    direct evaluation gives: knob `half_gates` 1 (default) / 0, against the oracle (which evaluates every gate on every row),
+    with public inputs (PoseidonGate rows next to them), on the 135-wire configuration, and on an unsatisfied witness."""
+    out = pkg.make_circuit(d, mix, 53, num_public_inputs=npi, num_wires=W)
+    blob, wires = out[0], out[1]
+    pis = out[2] if npi else ()
+    want = orc.OracleCircuit(blob).prove(wires, public_inputs=pis)[0]
+    cd = pkg.CircuitData(blob)
+    cd.set("profile", 2)
+    assert cd.prove(wires, public_inputs=pis).to_bytes() == want
+    ran = any(k.startswith("gate_sums_kernel") for k in cd.kernel_stats())
+    assert ran == (mix == "ecdsa"), "the half-domain path runs exactly where a gate of degree <= 4 has >= 48 constraints"
+    cd.set("profile", 0)
+    cd.set("half_gates", 0)
+    cd.set("profile", 2)
+    assert cd.prove(wires, public_inputs=pis).to_bytes() == want
+    assert not any(k.startswith("gate_sums_kernel") for k in cd.kernel_stats())
+    cd.set("profile", 0)
+    cd.set("half_gates", 1)
+    # a witness that breaks a range-checked limb of a half-domain gate: the identity fails at zeta whichever way the sums were made
+    import torch
+    bad = wires.copy()
+    rows = np.nonzero((bad[W - 40] > 0) & (bad[W - 40] < 4))[0]    # a 2-bit limb of a U32 gate row (not the PublicInputGate row's random filler)
+    if len(rows):
+        bad[W - 40, rows[0]] = (int(bad[W - 40, rows[0]]) + 1) % P
+        with pytest.raises(pkg.P2GpuError) as e:
+            cd.prove(bad, public_inputs=pis)
+        assert e.value.code == -5
+    assert cd.prove(torch.from_numpy(wires.view(np.int64)).cuda(), public_inputs=pis).to_bytes() == want
+    cd.close()
+
+
+@pytest.mark.parametrize("env", [{"P2GPU_HOST_PRESCAN": "0"}, {"P2GPU_NTT_DIRECT": "0", "P2GPU_LEAF_LEVELS": "0"}, {"P2GPU_HALF_GATES": "0"}])
 def test_measurement_switches_keep_the_bytes(pkg, gpu, env):
     """The A/B switches select the older kernels / paths (the whole wire matrix over PCIe; the generic NTT passes and no tree
     levels inside the leaf hash -- the one-lane tree tails of rounds 1-2 behind P2GPU_COOP_TAIL left the tree in round 5): read once per process, so a child process proves a golden circuit with the switch set and the digest
@@ -1132,6 +1168,7 @@ def test_seeded_differential_fuzz(pkg, orc, gpu):
                 cd.set("self_check", 0 if mutated else 1)
                 cd.set("zero_columns", int(rng.integers(0, 4) != 0))
                 cd.set("virtual_columns", int(rng.integers(0, 3) != 0))
+                cd.set("half_gates", int(rng.integers(0, 3) != 0))
                 expect, _ = oc.prove(w, public_inputs=pis)
                 tag = (it, rnd, d, mix, seed, npi, nw, routed_only)
                 assert cd.prove(w, public_inputs=pis).to_bytes() == expect, ("host",) + tag

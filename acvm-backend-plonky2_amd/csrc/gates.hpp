@@ -23,6 +23,14 @@ enum {
   G_COMPARISON = 11, G_KIND_COUNT
 };
 
+// unroll factor of the 2-bit limb loops of the U32 gates (each iteration: one wire load, a range check, a Horner step): the
+// loads of an unrolled body are issued together -- the memory-level parallelism of a wave in the gate kernels
+#ifndef P2_LIMB_UNROLL
+#define P2_LIMB_UNROLL 8
+#endif
+#define P2_PRAGMA_(x) _Pragma(#x)
+#define P2_PRAGMA(x) P2_PRAGMA_(x)
+
 struct GateDesc {
   uint32_t kind, p[4];
   uint32_t sel_index, group_start, group_end;
@@ -113,8 +121,10 @@ struct ExtOps {
 };
 
 template <class F>
-P2_HD typename F::T range4(typename F::T v) {  // v (v-1) (v-2) (v-3) = u (u + 2), u = v^2 - 3v: two products
-  typename F::T u = F::sub(F::mul(v, v), F::add(F::dbl(v), v));
+P2_HD typename F::T range4(typename F::T v) {  // v (v-1) (v-2) (v-3) = u (u + 2), u = v (v - 3): two products
+  // u as a congruent word (its consumers: the first operand of an addition, a product): 45 VALU instead of the 62 of
+  // "v^2 canonical, 3v by two additions, a subtraction" -- 192 of a U32ArithmeticGate's 216 constraints are this
+  typename F::T u = F::mul_out(v, F::sub(v, F::from(3)));
   return F::mul_out(u, F::add(u, F::from(2)));  // (every caller hands the result to out.emit)
 }
 template <class F>
@@ -374,7 +384,7 @@ P2_HD void eval_gate(const GateDesc &g, WF W, CF LC, const typename F::T *pih, c
       out.emit(F::sub(combined, computed));
       typename F::Horner cl, ch;
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 8
+P2_PRAGMA(unroll P2_LIMB_UNROLL)
 #endif
       for (uint32_t j = 32; j-- > 0;) {
         T limb = W(6 * ops + 32 * i + j);
@@ -419,7 +429,7 @@ P2_HD void eval_gate(const GateDesc &g, WF W, CF LC, const typename F::T *pih, c
       out.emit(F::sub(res, F::add(init, F::mul(bout, F::from(1ULL << 32)))));
       typename F::Horner comb;
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 8
+P2_PRAGMA(unroll P2_LIMB_UNROLL)
 #endif
       for (uint32_t j = 16; j-- > 0;) {
         T limb = W(5 * ops + 16 * i + j);
@@ -436,12 +446,12 @@ P2_HD void eval_gate(const GateDesc &g, WF W, CF LC, const typename F::T *pih, c
     for (uint32_t i = 0; i < nl; i++) {
       typename F::Horner sum;
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 8
+P2_PRAGMA(unroll P2_LIMB_UNROLL)
 #endif
       for (uint32_t j = 16; j-- > 0;) sum.push(W(nl + 16 * i + j), 2);
       out.emit(F::sub(sum.value(), W(i)));
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 8
+P2_PRAGMA(unroll P2_LIMB_UNROLL)
 #endif
       for (uint32_t j = 0; j < 16; j++) out.emit(range4<F>(W(nl + 16 * i + j)));
     }

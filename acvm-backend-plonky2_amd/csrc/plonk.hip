@@ -311,21 +311,32 @@ __global__ __launch_bounds__(256, P2_QUOT_WAVES) void quotient_kernel(const Quot
 // words the direct evaluation gives (tests: proofs bit-exact, knob "half_gates" 0 / 1).  synth(19, ecdsa): 855 of 940
 // constraints per row are such gates.
 // out: hsum [parity][m][slot * K + c][n] (coset r = 2 m + parity); this kernel writes parity 0.
-template <int G>
-__global__ __launch_bounds__(256, P2_QUOT_WAVES) void gate_sums_kernel(const QuotArgs a) {
+#ifndef P2_SUMS_WAVES
+#define P2_SUMS_WAVES 8  // 64 VGPRs: measured 1.02 ms against 1.065 at 6 and 1.14 at 5 waves per SIMD (synth(17, ecdsa), staged sums)
+#endif
+// STAGE: the sums wait in LDS until every gate is done and go to memory at the end.  Not for bandwidth: a global store inside
+// the gate loop makes every later uniform load (the alpha powers: two per constraint) a VECTOR load -- hipcc may only use the
+// scalar unit for memory no store of the kernel can have touched -- and each of those waits out a full L2 round trip in front of
+// its multiply-accumulate (round 6, first version: 73 % of the wave cycles in s_waitcnt, 1.46 ms; profiles/r06_gate_sums.md).
+template <int G, bool STAGE>
+__global__ __launch_bounds__(256, P2_SUMS_WAVES) void gate_sums_kernel(const QuotArgs a) {
+  extern __shared__ gl_t sums_stage[];  // [nsk][rows of the block]
   const uint32_t grp = G > 1 ? threadIdx.y : 0;
   const uint32_t n = 1u << a.d;
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t m = blockIdx.y, r = 2u * m;
   if (k >= n) return;
   const uint32_t ncs = a.NC + a.R;
-  const gl_t *cs = a.cs_lde + (size_t)r * ncs * n + k;
-  const gl_t *wl = a.wires_lde + (size_t)r * a.W * n + k;   // (only with every coset local: z = r)
+  // (uniform base + the lane's row as a 32-bit index: the loads take the base from SGPRs and one VGPR offset -- no 64-bit
+  // address arithmetic per wire, no address registers: more loads in flight under the same register budget)
+  const gl_t *csb = a.cs_lde + (size_t)r * ncs * n;
+  const gl_t *wlb = a.wires_lde + (size_t)r * a.W * n;   // (only with every coset local: z = r)
   Consumer out;
   out.ap0 = a.apow;
   out.ap1 = a.apow + a.nterms;
-  auto W = [&](uint32_t c) { return wl[(size_t)c * n]; };
-  auto LC = [&](uint32_t i) { return cs[(size_t)(a.num_selectors + i) * n]; };
+  const uint32_t kb = k * 8u;  // (n <= 2^24 rows: a 32-bit byte offset)
+  auto W = [&](uint32_t c) { return *(const gl_t *)((const char *)(wlb + (size_t)c * n) + kb); };
+  auto LC = [&](uint32_t i) { return *(const gl_t *)((const char *)(csb + (size_t)(a.num_selectors + i) * n) + kb); };
   for (uint32_t gi = 0; gi < a.num_gates; gi++) {
     const GateDesc g = a.gates[gi];
     const uint32_t slot1 = gate_half_slot(g);
@@ -335,9 +346,27 @@ __global__ __launch_bounds__(256, P2_QUOT_WAVES) void gate_sums_kernel(const Quo
     out.acc1.clear();
     out.t = a.K + a.K * a.nchunks;
     eval_gate<BaseOps, false>(g, W, LC, a.pi_hash, c_poseidon_rc, out);
-    gl_t *h = a.hsum + ((size_t)m * a.nsk + (size_t)(slot1 - 1) * a.K) * n + k;
-    h[0] = out.acc0.value();
-    if (a.K > 1) h[n] = out.acc1.value();
+    if constexpr (STAGE) {
+      const uint32_t rb = blockDim.x, sk = (slot1 - 1) * a.K;
+      sums_stage[sk * rb + threadIdx.x] = out.acc0.value();
+      if (a.K > 1) sums_stage[(sk + 1) * rb + threadIdx.x] = out.acc1.value();
+    } else {
+      gl_t *h = a.hsum + ((size_t)m * a.nsk + (size_t)(slot1 - 1) * a.K) * n + k;
+      h[0] = out.acc0.value();
+      if (a.K > 1) h[n] = out.acc1.value();
+    }
+  }
+  if constexpr (STAGE) {
+    // every lane reads back what it wrote itself (same wave, LDS operations in order): no barrier
+    for (uint32_t gi = 0; gi < a.num_gates; gi++) {
+      const GateDesc g = a.gates[gi];
+      const uint32_t slot1 = gate_half_slot(g);
+      if (!slot1 || (G > 1 && gate_sums_group(g) != grp)) continue;
+      const uint32_t rb = blockDim.x, sk = (slot1 - 1) * a.K;
+      gl_t *h = a.hsum + ((size_t)m * a.nsk + sk) * n + k;
+      h[0] = sums_stage[sk * rb + threadIdx.x];
+      if (a.K > 1) h[n] = sums_stage[(sk + 1) * rb + threadIdx.x];
+    }
   }
 }
 // even cosets -> odd cosets, between the per-coset inverse and forward transforms: in [m][col][n] = coefficients (bit-reversed
@@ -366,10 +395,21 @@ __global__ __launch_bounds__(256) void gate_sums_cross_kernel(const gl_t *__rest
 }
 void gate_sums_eval(hipStream_t st, const QuotArgs &a, uint32_t groups) {
   const uint32_t n = 1u << a.d;
-  const char *name = groups == 4 ? "gate_sums_kernel<4>" : "gate_sums_kernel<1>";
+  const char *name = groups == 4 ? "gate_sums_kernel<4>" : "gate_sums_kernel<1>";  // (either staging form)
   ProfScope ps(name, 8.0 * (double)n * 4 * (a.W + a.num_selectors + 1.0 * a.nsk));
-  if (groups == 4) hipLaunchKernelGGL((gate_sums_kernel<4>), dim3(n / 64, 4), dim3(64, 4), 0, st, a);
-  else hipLaunchKernelGGL((gate_sums_kernel<1>), dim3((n + 255) / 256, 4), dim3(256), 0, st, a);
+  const size_t lds = (size_t)a.nsk * (groups == 4 ? 64 : 256) * sizeof(gl_t);
+  static const bool stage_ok = [] {
+    const char *e = getenv("P2GPU_SUMS_STAGE");  // 0: store from inside the gate loop (A/B measurements)
+    return !(e && *e == '0');
+  }();
+  const bool stage = stage_ok && lds <= 24 * 1024;
+  if (groups == 4) {
+    if (stage) hipLaunchKernelGGL((gate_sums_kernel<4, true>), dim3(n / 64, 4), dim3(64, 4), lds, st, a);
+    else hipLaunchKernelGGL((gate_sums_kernel<4, false>), dim3(n / 64, 4), dim3(64, 4), 0, st, a);
+  } else {
+    if (stage) hipLaunchKernelGGL((gate_sums_kernel<1, true>), dim3((n + 255) / 256, 4), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((gate_sums_kernel<1, false>), dim3((n + 255) / 256, 4), dim3(256), 0, st, a);
+  }
 }
 void gate_sums_cross(hipStream_t st, const gl_t *in, const gl_t *inv_scale, gl_t *out, uint32_t d, uint32_t cols, const gl_t F[16]) {
   const uint32_t n = 1u << d;

@@ -25,7 +25,7 @@ lone = (time.time() - t0) / 8 * 1e3
 cd.set("profile", 1)
 for _ in range(4): cd.prove(wd)
 st = cd.kernel_stats()
-print("$spec", "lone %.3f ms" % lone, {k: round(v["ms"] / 4, 4) for k, v in st.items() if "ntt_" in k or "quotient_kernel" in k or "hash_lde" in k})
+print("$spec", "lone %.3f ms" % lone, {k: round(v["ms"] / 4, 4) for k, v in st.items() if "ntt_" in k or "quotient_kernel" in k or "hash_lde" in k or "gate_sums" in k or "poseidon" in k})
 PY
 done
 done

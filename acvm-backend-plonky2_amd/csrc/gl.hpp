@@ -205,6 +205,22 @@ P2_HD gl_t gl_add(gl_t a, gl_t b) { return gl_add_c(a, b); }
 P2_HD gl_t gl_sub(gl_t a, gl_t b) { return gl_sub_c(a, b); }
 P2_HD gl_t gl_reduce128(uint64_t lo, uint64_t hi) { return gl_reduce128_c(lo, hi); }
 #endif
+#if defined(__HIPCC__)
+// A load the scalar unit may always take: hipcc turns a uniform load into s_load only while no store of the kernel can have
+// touched the memory before it, so ONE global store inside a loop makes every uniform table look-up of the later iterations a
+// vector load that waits out an L2 round trip (round 6: the alpha powers of the gate kernels, the column classes / scalars of
+// the leaf hash).  Through the constant address space the load is scalar whatever the kernel stores -- for tables the kernel
+// itself never writes.  (A non-uniform address still gives correct code: a vector load.)
+template <class T>
+__device__ __forceinline__ T ld_uniform(const T *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const T __attribute__((address_space(4))) *cptr;
+  return *(cptr)(uintptr_t)p;
+#else
+  return *p;
+#endif
+}
+#endif
 P2_HD gl_t gl_neg(gl_t a) { return a ? GL_P - a : 0; }
 P2_HD gl_t gl_dbl(gl_t a) { return gl_add(a, a); }
 

@@ -138,8 +138,8 @@ __device__ __forceinline__ dig_t hash_or_noop(uint32_t nwords, F get, const gl_t
 // stored, so the digest is the same.
 __device__ __forceinline__ gl_t virt_get(const VirtCols &v, uint32_t i, gl_t Lk, const gl_t *base, size_t n) {
   if (i >= v.first) {
-    const uint32_t cl = v.cls[i];
-    if (cl < 2u) return cl == 1u ? gl_mul(v.val[i], Lk) : (gl_t)0;  // (class 3 is materialised like a dense column)
+    const uint32_t cl = ld_uniform(v.cls + i);  // (scalar loads even in the kernels that store digests inside their loop)
+    if (cl < 2u) return cl == 1u ? gl_mul(ld_uniform(v.val + i), Lk) : (gl_t)0;  // (class 3 is materialised like a dense column)
   }
   return base[(size_t)i * n];
 }

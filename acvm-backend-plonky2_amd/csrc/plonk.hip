@@ -395,14 +395,15 @@ __global__ __launch_bounds__(256) void gate_sums_cross_kernel(const gl_t *__rest
 }
 void gate_sums_eval(hipStream_t st, const QuotArgs &a, uint32_t groups) {
   const uint32_t n = 1u << a.d;
-  const char *name = groups == 4 ? "gate_sums_kernel<4>" : "gate_sums_kernel<1>";  // (either staging form)
-  ProfScope ps(name, 8.0 * (double)n * 4 * (a.W + a.num_selectors + 1.0 * a.nsk));
   const size_t lds = (size_t)a.nsk * (groups == 4 ? 64 : 256) * sizeof(gl_t);
   static const bool stage_ok = [] {
     const char *e = getenv("P2GPU_SUMS_STAGE");  // 0: store from inside the gate loop (A/B measurements)
     return !(e && *e == '0');
   }();
   const bool stage = stage_ok && lds <= 24 * 1024;
+  // (same spelling as rocprofv3's demangled names)
+  const char *name = groups == 4 ? (stage ? "gate_sums_kernel<4, true>" : "gate_sums_kernel<4, false>") : (stage ? "gate_sums_kernel<1, true>" : "gate_sums_kernel<1, false>");
+  ProfScope ps(name, 8.0 * (double)n * 4 * (a.W + a.num_selectors + 1.0 * a.nsk));
   if (groups == 4) {
     if (stage) hipLaunchKernelGGL((gate_sums_kernel<4, true>), dim3(n / 64, 4), dim3(64, 4), lds, st, a);
     else hipLaunchKernelGGL((gate_sums_kernel<4, false>), dim3(n / 64, 4), dim3(64, 4), 0, st, a);

@@ -90,7 +90,7 @@ def survey_bytes(d, W, CS, K=2, PP=9, QF=8):
 # kernel symbol (prefix) -> prover step of survey_bytes()
 KERNEL_STEP = [
     ("ntt_pass_kernel<1,", "lde"), ("ntt_dit_", "lde"), ("lde_", "lde"), ("ntt_pass_kernel<0,", "intt"), ("ntt_dif_", "intt"), ("intt_", "intt"),
-    ("hash_lde", "leaf_hash"), ("merkle", "merkle"), ("zs_", "zs"), ("quotient", "quotient"), ("poseidon_gate", "quotient"),
+    ("hash_lde", "leaf_hash"), ("merkle", "merkle"), ("zs_", "zs"), ("quotient", "quotient"), ("poseidon_gate", "quotient"), ("gate_sums", "quotient"),
     ("eval_columns", "openings_fri_reduce"), ("reduce_columns", "openings_fri_reduce"),
     ("structured_fill", "lde"), ("column_nonzero", "intt"),   # the structured columns' share of those steps
 ]

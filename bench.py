@@ -662,7 +662,7 @@ def main():
 
     d, mix = args.degree_bits, args.mix
     global PROFILE_KEY
-    PROFILE_KEY = (mix if args.workload == "synth" else "sha256", d)
+    PROFILE_KEY = (("poseidon" if args.hasher == "poseidon" and mix == "sha" else mix) if args.workload == "synth" else "sha256", d)
     # every rank proves its own witness of the same circuit shape (independent proofs)
     sharded = args.mode == "sharded" and world > 1
     if args.workload == "sha256":

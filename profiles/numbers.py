@@ -27,6 +27,67 @@ def f(x, nd=2):
     return "–" if x is None else (f"{x:.{nd}f}" if isinstance(x, float) else str(x))
 
 
+# ---- instruction budget per proof and the floor it implies ---------------------------------------------
+# Ceilings (profiles/r03_ubench.txt, MI355X at 2.38 GHz, 8 waves per SIMD): half-rate class 37.7 T lane-instr/s (every carry,
+# multiply, compare: all of the field arithmetic); the Keccak-f round mix (120 v_bitop3 + 58 v_alignbit) 49.9 T as an interleaved stream.
+HALF_T, KECCAK_T = 37.7e12, 49.9e12
+CLASSES = [("Keccak (leaf hashes, tree levels, FRI leaves, PoW)", ("hash_lde_leaves_kf", "hash_lde_absorb_kf", "merkle_level_kf", "merkle_levels_kf", "merkle_coop_kernel",
+                                                                 "hash_fri_leaves_kernel<0", "hash_lde_leaves_kernel<0", "hash_rows", "merkle_level_kernel<0", "pow_kernel"), KECCAK_T),
+           ("Poseidon hashing (PoseidonGoldilocksConfig)", ("hash_lde_leaves_kernel<1", "hash_fri_leaves_kernel<1", "merkle_level_kernel<1", "merkle_coop_poseidon", "hash_fri_leaves_coop_poseidon"), HALF_T),
+           ("NTT (inverse transforms, LDE, FRI)", ("ntt_", "structured_fill", "column_"), HALF_T),
+           ("quotient (permutation argument, gates, Z / partial products)", ("quotient", "gate_sums", "poseidon_gate", "zs_", "scan_"), HALF_T)]
+
+
+def instruction_budget(tag):
+    """Lane-instructions per proof by class from the committed SQ passes (profiles/<tag>_<workload>_sq_summary.json: SQ_INSTS_VALU per
+    launch x 64 lanes x launches / proofs) and the time each class needs at the ceiling of its instruction mix: the floor of a proof
+    on one MI355X whatever the overlap -- what `ms_per_step` is to be judged against."""
+    rows = []
+    for wl, label, bench in (("sha17", "synth(17, sha)", "bench"), ("ecdsa17", "synth(17, ecdsa)", "bench_d17_ecdsa"), ("grammar17", "synth(17, grammar)", None),
+                             ("poseidon17", "synth(17, sha), Poseidon hasher", "bench_poseidon")):
+        sq = load(os.path.join(here, f"{tag}_{wl}_sq_summary.json"))
+        if not sq:
+            continue
+        ks = sq["kernels"]
+        proofs = max((v["launches"] for k, v in ks.items() if k.startswith(("quotient_kernel", "zs_chunk_kernel"))), default=0)
+        if not proofs:
+            continue
+        tot = {c[0]: 0.0 for c in CLASSES}
+        tot["rest (openings, FRI reduce / fold / quotient, gather)"] = 0.0
+        for k, v in ks.items():
+            li = v["SQ_INSTS_VALU"] * 64.0 * v["launches"] / proofs
+            for name, pres, _ in CLASSES:
+                if k.startswith(pres):
+                    tot[name] += li
+                    break
+            else:
+                tot["rest (openings, FRI reduce / fold / quotient, gather)"] += li
+        ceil = {c[0]: c[2] for c in CLASSES}
+        floor_ms = sum(v / ceil.get(k, HALF_T) for k, v in tot.items()) * 1e3
+        b = load(os.path.join(here, f"{tag}_{bench}.json")) if bench else None
+        rows.append((label, tot, floor_ms, b))
+        if wl in ("grammar17", "sha17"):   # the 2^24-row configurations: 16 x the rows; the transforms also grow by the layer count
+            mixn = wl[:-2]
+            big = {k: v * 16 * (24.0 / 20.0 if k.startswith("NTT") else 1.0) for k, v in tot.items()}
+            fl = sum(v / ceil.get(k, HALF_T) for k, v in big.items()) * 1e3
+            rows.append((f"synth(21, {mixn}) — scaled from the 2^20-row pass", big, fl, load(os.path.join(here, f"{tag}_bench_d21_{mixn}.json"))))
+    if not rows:
+        return []
+    out = ["", "## Instruction budget per proof and the floor it implies\n",
+           "Lane-instructions per proof by class (SQ_INSTS_VALU x 64 from the committed SQ passes, `profiles/" + tag + "_*_sq_summary.json`) and the time each class "
+           "needs at the ceiling of its own instruction mix (half-rate class 37.7 T lane-instr/s; the Keccak-f round mix 49.9 T: `profiles/r03_ubench.txt`): the floor of "
+           "one proof on one MI355X whatever the overlap.  2^24 rows: x16 for everything but the transforms, whose count per element grows with the "
+           "layers (x16 x 24/20 for the LDE).\n",
+           "| workload | " + " | ".join(k.split(" (")[0] for k in rows[0][1]) + " | total G lane-instr | floor ms | measured ms/step at `value` (lone) | floor / measured |",
+           "|---|" + "---|" * (len(rows[0][1]) + 4)]
+    for label, tot, floor_ms, b in rows:
+        cells = " | ".join(f"{v / 1e9:.1f} G" for v in tot.values())
+        ms = b.get("ms_per_step") if b else None
+        lone = b.get("latency_ms_single_proof") if b else None
+        out.append(f"| {label} | {cells} | {sum(tot.values()) / 1e9:.1f} | {floor_ms:.2f} | {f(ms, 2)} ({f(lone, 2)}) | {f(floor_ms / ms if ms else None, 2)} |")
+    return out
+
+
 def main():
     tags = sorted({re.match(r"^(r\d+[a-z]?)_bench", os.path.basename(p)).group(1) for p in glob.glob(os.path.join(here, "r*_bench*.json"))})
     tag = sys.argv[1] if len(sys.argv) > 1 else tags[-1]
@@ -106,6 +167,7 @@ def main():
     if gr:
         out += ["", f"`bench.py --group 0,0` (every proof sharded over a two-rank device group on one GPU): {f(gr['ms_per_step'], 2)} ms per proof resident, "
                 f"{f(gr.get('latency_ms_single_proof_host_witness'), 2)} ms with the host witness."]
+    out += instruction_budget(tag)
     open(os.path.join(here, "NUMBERS.md"), "w").write("\n".join(out) + "\n")
     print("\n".join(out))
     # a fraction of a peak above 1 means a numerator or a denominator is not what its column says (a 1.124 was

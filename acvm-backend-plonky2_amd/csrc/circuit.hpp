@@ -273,7 +273,7 @@ struct CircuitState {
   DBuf<gl_t> xchg_recv;
   // ONE process driving several GPUs (p2gpu_init with n > 1 device ids): the handle the caller holds is rank 0 of a
   // group and owns ranks 1..; every prove call fans out over one host thread per rank, and the exchanges of the
-  // sharded proof are peer-to-peer copies between the ranks' own streams (PeerGroup, prover.hip) -- no RCCL, no
+  // sharded proof are peer-to-peer copies between the ranks' own streams (PeerGroup, transport.hpp) -- no RCCL, no
   // second process, which is the shape the reference's single `prove` call site (prove_action.rs:96) can drive
   std::vector<p2gpu_circuit *> group;     // ranks 1..world-1 (empty: an ordinary handle)
   struct PeerGroup *peer = nullptr;       // shared by the ranks of a group, owned by rank 0
@@ -305,7 +305,7 @@ struct CircuitState {
 struct p2gpu_circuit : p2::CircuitState {};
 
 namespace p2 {
-extern void (*g_circuit_release)(p2gpu_circuit *);  // hostcore.hip; set by prover.hip
+extern void (*g_circuit_release)(p2gpu_circuit *);  // hostcore.hip; set by handle.hip
 void use_hasher(const p2gpu_circuit *c);  // select the handle's hasher for this thread (hostcore.hip)
 void shard_assemble_cap(int world, unsigned rate_bits, size_t cap_per, const dig_t *gathered, std::vector<dig_t> &cap);
 // blob header + gate table + (optional) cap + k_is -> the host-side fields of the handle; leaves

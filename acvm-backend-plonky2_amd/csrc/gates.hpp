@@ -37,7 +37,7 @@ struct GateDesc {
   uint32_t num_constraints, degree, num_constants, pad;  // pad: evaluation group (quotient kernel, heavy mixes)
 };
 
-// GateDesc.pad, set at circuit create (prover.hip): which wave of a four-wave block evaluates the gate, and whether its folded
+// GateDesc.pad, set at circuit create (handle.hip): which wave of a four-wave block evaluates the gate, and whether its folded
 // constraint sum comes from the half-domain evaluation (plonk.hip gate_sums_kernel)
 //   bits 0-3   group when every gate is evaluated directly on every row
 //   bits 4-7   group in the main kernel when the half-domain gates are looked up there

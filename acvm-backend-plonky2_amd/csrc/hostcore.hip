@@ -47,7 +47,7 @@ void shard_assemble_cap(int world, unsigned rate_bits, size_t cap_per, const dig
         cap[(size_t)bitrev32((uint32_t)q + z * (uint32_t)world, rate_bits) * cap_per + bitrev32((uint32_t)k, lgp)] =
             gathered[((size_t)q * CL + z) * cap_per + k];
 }
-// set by prover.hip (the TU that owns device memory): releases a prover handle's device state
+// set by handle.hip (the TU that creates and releases the device state): releases a prover handle's device state
 void (*g_circuit_release)(p2gpu_circuit *) = nullptr;
 }  // namespace p2
 

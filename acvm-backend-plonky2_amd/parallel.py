@@ -102,7 +102,7 @@ def max_over_ranks(seconds, group=None):
 
 
 def intt_blocks(dense, world_size):
-    """Column blocks of the column-sharded inverse transform (knob `shard_intt`; csrc/prover.hip intt_blocks): the sorted list of
+    """Column blocks of the column-sharded inverse transform (knob `shard_intt`; csrc/transport.hip intt_blocks): the sorted list of
     dense columns is dealt out in `world_size` contiguous runs whose sizes differ by at most one; rank p's block is the column
     range [first, last + 1) of its run -- what it transforms and what it sends (structured columns in between ride along).
     -> [(lo, hi)] per rank, (0, 0) for a rank with no dense column."""

@@ -202,6 +202,29 @@ def counter_clock(kernel, wave_instr_per_launch, launches_per_sec):
     return {}
 
 
+def valu_floor(ms_per_proof_per_gpu):
+    """What the proof is really bound by: its VALU instructions.  Lane-instructions per proof by class from the committed
+    SQ pass of THIS workload and the time they need at the ceilings of their mixes (profiles/numbers.py budget_of: Keccak-f stream
+    49.9 T lane-instr/s, field arithmetic 37.7 T) -- the floor of one proof on one GPU whatever the overlap -- next to the
+    measured time per proof at `value`.  None when this (mix, degree_bits) has no committed SQ pass."""
+    f = newest("r*_sq_summary.json")
+    if not f:
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("p2_numbers", os.path.join(ROOT, "profiles", "numbers.py"))
+        nb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(nb)
+        with open(f) as fh:
+            tot, floor_ms = nb.budget_of(json.load(fh))
+        if tot is None:
+            return None
+        return {"lane_instr_per_proof": sum(tot.values()), "floor_ms_per_proof": floor_ms, "measured_ms_per_proof_at_value": ms_per_proof_per_gpu,
+                "frac_of_floor": floor_ms / ms_per_proof_per_gpu if ms_per_proof_per_gpu else None, "source": os.path.basename(f)}
+    except Exception:
+        return None
+
+
 def issue_roofline(kernel, launches_per_sec):
     """VALU issue side of a kernel: lane-instructions per launch from the committed SQ pass (SQ_INSTS_VALU x 64) x live
     launches/s of kernel time, against the guide's peak and against the ceiling of the kernel's own instruction mix."""
@@ -275,7 +298,8 @@ def compact_line(out, detail_name="bench_detail.json"):
             "hbm": {"frac": r.get("frac")},
             "valu_issue": ({"frac": iss.get("frac"), "frac_of_mix_ceiling": iss.get("frac_of_mix_ceiling"), "peak": iss.get("peak"),
                             "unit": iss.get("unit"), "source": iss.get("source")} if iss else None),
-            "whole_proof": {"algorithmic_bytes": wp.get("algorithmic_bytes"), "frac_lone": wp.get("frac"), "frac_at_value": wp.get("frac_at_throughput")},
+            "whole_proof": {"algorithmic_bytes": wp.get("algorithmic_bytes"), "frac_lone": wp.get("frac"), "frac_at_value": wp.get("frac_at_throughput"),
+                            "valu_floor": wp.get("valu_floor")},
         }
     cb = out.get("cpu_baseline")
     if cb:
@@ -1142,7 +1166,8 @@ def main():
                 "whole_proof": {"algorithmic_bytes": total_b, "achieved": total_b / (single_ms * 1e-3) / 1e9, "unit": "GB/s",
                                 "frac": total_b / (single_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                 "note": "B(N) / t_prove of SURVEY.md 8(d) with t_prove = latency_ms_single_proof",
-                                "frac_at_throughput": total_b * (total_proofs / world / dt) / 1e9 / HBM_PEAK_GBPS},
+                                "frac_at_throughput": total_b * (total_proofs / world / dt) / 1e9 / HBM_PEAK_GBPS,
+                                "valu_floor": valu_floor(ms_step * (1 if sharded else world))},
                 # every prover step by SURVEY 8(d)'s bytes over the summed LONE HIP-event time of its kernels (per proof)
                 # `frac` divides the bytes of the columns the step PROCESSED (dense wire columns: `dense_wire_columns`);
                 # `frac_incl_elided` is SURVEY 8(d)'s figure for all 270 columns over the same time

@@ -38,6 +38,27 @@ CLASSES = [("Keccak (leaf hashes, tree levels, FRI leaves, PoW)", ("hash_lde_lea
            ("quotient (permutation argument, gates, Z / partial products)", ("quotient", "gate_sums", "poseidon_gate", "zs_", "scan_"), HALF_T)]
 
 
+def budget_of(sq):
+    """(lane-instructions per proof by class, floor in ms) of one SQ summary (profiles/summarize.py's <tag>_<workload>_sq_summary.json)."""
+    ks = sq["kernels"]
+    proofs = max((v["launches"] for k, v in ks.items() if k.startswith(("quotient_kernel", "zs_chunk_kernel"))), default=0)
+    if not proofs:
+        return None, None
+    tot = {c[0]: 0.0 for c in CLASSES}
+    rest = "rest (openings, FRI reduce / fold / quotient, gather)"
+    tot[rest] = 0.0
+    for k, v in ks.items():
+        li = v["SQ_INSTS_VALU"] * 64.0 * v["launches"] / proofs
+        for name, pres, _ in CLASSES:
+            if k.startswith(pres):
+                tot[name] += li
+                break
+        else:
+            tot[rest] += li
+    ceil = {c[0]: c[2] for c in CLASSES}
+    return tot, sum(v / ceil.get(k, HALF_T) for k, v in tot.items()) * 1e3
+
+
 def instruction_budget(tag):
     """Lane-instructions per proof by class from the committed SQ passes (profiles/<tag>_<workload>_sq_summary.json: SQ_INSTS_VALU per
     launch x 64 lanes x launches / proofs) and the time each class needs at the ceiling of its instruction mix: the floor of a proof
@@ -48,22 +69,10 @@ def instruction_budget(tag):
         sq = load(os.path.join(here, f"{tag}_{wl}_sq_summary.json"))
         if not sq:
             continue
-        ks = sq["kernels"]
-        proofs = max((v["launches"] for k, v in ks.items() if k.startswith(("quotient_kernel", "zs_chunk_kernel"))), default=0)
-        if not proofs:
+        tot, floor_ms = budget_of(sq)
+        if tot is None:
             continue
-        tot = {c[0]: 0.0 for c in CLASSES}
-        tot["rest (openings, FRI reduce / fold / quotient, gather)"] = 0.0
-        for k, v in ks.items():
-            li = v["SQ_INSTS_VALU"] * 64.0 * v["launches"] / proofs
-            for name, pres, _ in CLASSES:
-                if k.startswith(pres):
-                    tot[name] += li
-                    break
-            else:
-                tot["rest (openings, FRI reduce / fold / quotient, gather)"] += li
         ceil = {c[0]: c[2] for c in CLASSES}
-        floor_ms = sum(v / ceil.get(k, HALF_T) for k, v in tot.items()) * 1e3
         b = load(os.path.join(here, f"{tag}_{bench}.json")) if bench else None
         rows.append((label, tot, floor_ms, b))
         if wl in ("grammar17", "sha17"):   # the 2^24-row configurations: 16 x the rows; the transforms also grow by the layer count

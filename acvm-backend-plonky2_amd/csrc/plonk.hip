@@ -424,7 +424,10 @@ void gate_sums_cross(hipStream_t st, const gl_t *in, const gl_t *inv_scale, gl_t
 // per LDE row are as much work as the rest of the row together, and inside the generic kernel they
 // set its register budget (155 VGPRs -> 3 waves per SIMD).  Adds filter(x) * sum_t alpha^t c_t / Z_H(x)
 // to what quotient_kernel wrote.
-__global__ __launch_bounds__(256) void poseidon_gate_kernel(const QuotArgs a, uint32_t gi) {
+#ifndef P2_PGATE_WAVES
+#define P2_PGATE_WAVES 6  // 80 VGPRs: 0.646 ms against 0.685 at 4 waves per SIMD (107 VGPRs), synth(17, sha) + 4 public inputs
+#endif
+__global__ __launch_bounds__(256, P2_PGATE_WAVES) void poseidon_gate_kernel(const QuotArgs a, uint32_t gi) {
   const uint32_t n = 1u << a.d;
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t z = blockIdx.y;

@@ -1,6 +1,6 @@
 """Randomised GPU-vs-oracle differential run: random (degree, gate mix, seed, public inputs, width), random
 structure of the unused wire columns (zeroed, extra rows, values in the PoseidonGate rows), random knobs
-(zero_columns / virtual_columns toggled between proofs on one handle), every entry point (host matrix, resident,
+(zero_columns / virtual_columns / half_gates toggled between proofs on one handle), every entry point (host matrix, resident,
 routed when the witness allows it, sparse with a random split)."""
 import sys
 import numpy as np
@@ -12,7 +12,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0
 for it in range(N):
-    d = int(rng.integers(5, 14)); mix = ["arith", "sha", "ecdsa"][int(rng.integers(0, 3))]
+    d = int(rng.integers(5, 15)); mix = ["arith", "sha", "ecdsa", "ecdsa", "grammar"][int(rng.integers(0, 5))]
     seed = int(rng.integers(1, 1 << 30)); npi = int(rng.choice([0, 0, 1, 4, 9, 17, 30])); nw = int(rng.choice([234, 234, 135]))
     routed_only = bool(rng.integers(0, 2))
     if nw == 135 and mix == "ecdsa" and npi == 0 and d < 6: d = 6
@@ -39,6 +39,7 @@ for it in range(N):
         cd.set("self_check", 0 if mutated else 1)
         cd.set("zero_columns", int(rng.integers(0, 4) != 0))
         cd.set("virtual_columns", int(rng.integers(0, 3) != 0))
+        cd.set("half_gates", int(rng.integers(0, 3) != 0))   # round 6: gates of degree <= 4 on the even cosets only (d >= 10)
         expect, _ = oc.prove(w, public_inputs=pis)
         got = {"host": cd.prove(w, public_inputs=pis).to_bytes(),
                "dev": cd.prove(torch.from_numpy(w.view(np.int64)).cuda(), public_inputs=pis).to_bytes()}

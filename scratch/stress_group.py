@@ -11,7 +11,7 @@ pkg = entry.load_package()
 orc = entry.load_oracle()
 world = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 pkg.init([0] * world)
-cases = [(9, "ecdsa", 1, 3), (12, "sha", 2, 0), (13, "grammar", 3, 0)]
+cases = [(9, "ecdsa", 1, 3), (12, "sha", 2, 0), (13, "grammar", 3, 0), (11, "ecdsa", 4, 0)]
 handles = []
 for d, mix, seed, npi in cases:
     out = pkg.make_circuit(d, mix, seed, num_public_inputs=npi, pi_row_routed_only=True)
@@ -24,6 +24,8 @@ bad = []
 def work(i, n):
     cd, wh, wd, pis, expect = handles[i]
     for it in range(n):
+        if it % 7 == 0:
+            cd.set("shard_intt", (it // 7) % 2)   # round 6: column-sharded inverse transforms + in-place all-gather of the blocks, on and off
         if it % 5 == 3:
             p = cd.prove_routed(np.ascontiguousarray(wh[:80]), public_inputs=pis).to_bytes()
         else:

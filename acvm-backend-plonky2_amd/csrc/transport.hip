@@ -149,7 +149,23 @@ static int shard_allgatherv_impl(p2gpu_circuit *c, uint8_t *base, const size_t *
   }
   if (c->rccl_comm) {
     const RcclApi &r = rccl();
-    if (world == 1) return 0;  // one rank: its block is in place
+    if (world == 1) {
+      // one rank: its block is in place.  With "shard_exercise" the grouped send / receive pair itself still runs once -- to this
+      // rank, into the exchange scratch -- so that the symbols resolve and the grouped form executes on a one-GPU box
+      if (c->shard_exercise && sz[0] && r.Send && r.Recv && r.GroupStart && r.GroupEnd) {
+        const size_t nb = std::min(sz[0], std::min((size_t)1 << 20, c->xchg_recv.count * sizeof(gl_t)));
+        RCCL_TRY(r.GroupStart());
+        ncclResult_t a = r.Send(base + off[0], nb, ncclUint8, 0, (ncclComm_t)c->rccl_comm, c->stream);
+        ncclResult_t b = a == ncclSuccess ? r.Recv(c->xchg_recv.p, nb, ncclUint8, 0, (ncclComm_t)c->rccl_comm, c->stream) : a;
+        const ncclResult_t ge = r.GroupEnd();
+        if (a != ncclSuccess || b != ncclSuccess) {
+          set_err("grouped self send / receive failed: %s", r.GetErrorString(a != ncclSuccess ? a : b));
+          return P2GPU_E_DEVICE;
+        }
+        RCCL_TRY(ge);
+      }
+      return 0;
+    }
     if (!(r.Send && r.Recv && r.GroupStart && r.GroupEnd)) {
       set_err("librccl.so.1 has no ncclSend / ncclRecv: shard_intt needs them");
       return P2GPU_E_DEVICE;

@@ -773,7 +773,8 @@ def test_rccl_transport_single_rank(pkg, orc, gpu, d, mix, npi):
     cd.set("shard_exercise", 1)
     got = cd.prove(wires, public_inputs=pis).to_bytes()
     assert got == plain == orc.OracleCircuit(blob).prove(wires, public_inputs=pis)[0]
-    cd.set("shard_intt", 1)     # one rank owns every block: the transform runs block-wise, the exchange has no peer
+    cd.set("shard_intt", 1)     # one rank owns every block: the transform runs block-wise; the exchange has no peer, but the grouped
+                                # ncclSend / ncclRecv pair still executes once, to the rank itself (transport.hip, world 1 + shard_exercise)
     assert cd.prove(wires, public_inputs=pis).to_bytes() == plain
     cd.set("shard_intt", 0)
     cd.set("shard_exercise", 0)

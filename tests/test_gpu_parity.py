@@ -881,6 +881,28 @@ def test_poseidon_hasher_proofs_match_oracle(pkg, orc, gpu, d, mix, npi):
     cd.close()
 
 
+def test_poseidon_hasher_golden_digests_at_full_size(pkg, gpu):
+    """PoseidonGoldilocksConfig (X1) bit-exact at BASELINE configs[2]'s size: the ORACLE proved the bench workload under hasher 1 in the build
+    container (tests/golden/gen_poseidon_digest.py; its Poseidon is the plain form, round by round -- the device runs the partial rounds'
+    linear layers three at a time, poseidon.hpp); the GPU proof must have the same bytes, through the host-witness and the resident entry."""
+    import torch
+
+    for g in _gold("proof_digests_poseidon.json"):
+        out = pkg.make_circuit(g["degree_bits"], g["mix"], g["seed"], num_public_inputs=g["public_inputs"], hasher=g["hasher"])
+        blob, wires = out[0], out[1]
+        pis = out[2] if g["public_inputs"] else ()
+        assert hashlib.sha256(blob.tobytes()).hexdigest() == g["blob_sha256"] and hashlib.sha256(wires.tobytes()).hexdigest() == g["wires_sha256"]
+        cd = pkg.CircuitData(blob)
+        assert cd.hash_bytes() == 32
+        assert hashlib.sha256(cd.constants_sigmas_cap()).hexdigest() == g["constants_sigmas_cap_sha256"] and cd.circuit_digest().hex() == g["circuit_digest"]
+        proof = cd.prove(wires, public_inputs=pis)
+        assert proof.timings["pow_witness"] == g["pow_witness"] and len(proof) == g["proof_len"]
+        assert hashlib.sha256(proof.to_bytes()).hexdigest() == g["proof_sha256"]
+        assert hashlib.sha256(cd.prove(torch.from_numpy(wires.view(np.int64)).cuda(), public_inputs=pis).to_bytes()).hexdigest() == g["proof_sha256"]
+        cd.verify(proof)
+        cd.close()
+
+
 def test_poseidon_hasher_full_size_and_sharded_exercise(pkg, orc, gpu):
     """2^20 LDE rows with the Poseidon hasher: verifier acceptance (the oracle would take minutes), and the
     exchange steps of a sharded proof through RCCL with 32-byte digests."""

@@ -1001,8 +1001,29 @@ def main():
                             "exchanges_rank0": xst, "proof_bytes": len(pr1),
                             "witness": "resident on every rank's device (p2gpu_prove_dev)"}
             box["out"] = sharded_half_   # (what is measured so far survives a later leg that raises or hangs)
+            # ... and the same proof from ONE process driving all N devices (device group, peer copies): rank 0 starts it while the
+            # other ranks wait at the barrier with idle GPUs
+            if not args.no_group_probe:
+                gp = None
+                if rank == 0:
+                    import subprocess
+                    ndev = torch.cuda.device_count()
+                    ids = ",".join(str(i % ndev) for i in range(world))
+                    cmd = [sys.executable, os.path.abspath(__file__), "--group", ids, "--group-probe", "--degree-bits", str(d), "--mix", mix,
+                           "--public-inputs", str(args.public_inputs), "--hasher", args.hasher, "--sharded-steps", str(args.sharded_steps)]
+                    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                                            "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+                    try:
+                        r = subprocess.run(cmd, capture_output=True, text=True, timeout=120 * scale_, env=env)
+                        gp = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-400:]}
+                    except Exception as e:
+                        gp = {"error": str(e)[:300]}
+                barrier()
+                sharded_half_["group"] = gp
+            box["out"] = sharded_half_
             # the same proof with the inverse transforms of the wires / Z-PP column-sharded and the coefficient blocks all-gathered
-            # (knob shard_intt) instead of replicated: same bytes, the first multi-GPU lease decides the default
+            # (knob shard_intt) instead of replicated: same bytes, the first multi-GPU lease decides the default.  LAST:
+            # grouped send / receive with per-peer sizes has never run between real peers -- if it wedges, everything above is already in `box`
             try:
                 csh.set("shard_intt", 1)
                 pr2 = csh.prove(w1, public_inputs=pis1)
@@ -1025,25 +1046,6 @@ def main():
             csh.close()
             del w1
             torch.cuda.empty_cache()
-            # ... and the same proof from ONE process driving all N devices (device group, peer copies): rank 0 starts it while the
-            # other ranks wait at the barrier with idle GPUs
-            if not args.no_group_probe:
-                gp = None
-                if rank == 0:
-                    import subprocess
-                    ndev = torch.cuda.device_count()
-                    ids = ",".join(str(i % ndev) for i in range(world))
-                    cmd = [sys.executable, os.path.abspath(__file__), "--group", ids, "--group-probe", "--degree-bits", str(d), "--mix", mix,
-                           "--public-inputs", str(args.public_inputs), "--hasher", args.hasher, "--sharded-steps", str(args.sharded_steps)]
-                    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
-                                                                            "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
-                    try:
-                        r = subprocess.run(cmd, capture_output=True, text=True, timeout=120 * scale_, env=env)
-                        gp = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-400:]}
-                    except Exception as e:
-                        gp = {"error": str(e)[:300]}
-                barrier()
-                sharded_half_["group"] = gp
             box["out"] = sharded_half_
           except Exception as e:   # (the other ranks then wait in a collective until their own watchdog fires)
             box["exc"] = repr(e)

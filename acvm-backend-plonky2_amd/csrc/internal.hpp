@@ -176,7 +176,7 @@ struct QuotArgs {
 void quotient_eval(hipStream_t st, const QuotArgs &a);
 // folded constraint sums of the half-domain gates on the even cosets -> a.hsum parity 0 (groups: 1 or 4 waves per row tile)
 void gate_sums_eval(hipStream_t st, const QuotArgs &a, uint32_t groups);
-// in / out [4][cols][n]: per-coset interpolants of the even cosets -> coefficient arrays of the odd cosets (F: HalfGates::cross)
+// in / out [4][cols][n]: per-coset interpolants of the even cosets -> coefficient arrays of the odd cosets (F: CircuitState::half_cross)
 void gate_sums_cross(hipStream_t st, const gl_t *in, const gl_t *inv_scale, gl_t *out, uint32_t d, uint32_t cols, const gl_t F[16]);
 // out[r][k] = qconst[8 + r] * n_inv / (qconst[r] * w_n^k - 1): per circuit, so that the quotient kernel loads L_0
 // instead of inverting x - 1 on every row (~125 modmuls of the ~1 200 a row of the permutation argument costs)

@@ -327,8 +327,8 @@ __global__ __launch_bounds__(256, P2_SUMS_WAVES) void gate_sums_kernel(const Quo
   const uint32_t m = blockIdx.y, r = 2u * m;
   if (k >= n) return;
   const uint32_t ncs = a.NC + a.R;
-  // (uniform base + the lane's row as a 32-bit index: the loads take the base from SGPRs and one VGPR offset -- no 64-bit
-  // address arithmetic per wire, no address registers: more loads in flight under the same register budget)
+  // (column base uniform, the lane's row a 32-bit byte offset: hipcc folds the lane's part into ONE 64-bit base and forms each
+  // column's address with a scalar shift + one v_lshl_add_u64 -- it does not take the SGPR-base form of global_load here)
   const gl_t *csb = a.cs_lde + (size_t)r * ncs * n;
   const gl_t *wlb = a.wires_lde + (size_t)r * a.W * n;   // (only with every coset local: z = r)
   Consumer out;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, P2_SUMS_WAVES) void gate_sums_kernel(const Quo
 // even cosets -> odd cosets, between the per-coset inverse and forward transforms: in [m][col][n] = coefficients (bit-reversed
 // positions) of P_m(y) = S(s_2m y); with inv_scale[r][p] = s_r^-e (e = bitrev p) P'_m = sum_j w_8^(2 m j) A_j, A_j = (g^n)^j S_j[e]
 // (S = sum_j x^(j n) S_j), and the odd coset 2 m' + 1 wants sum_j w_8^((2 m' + 1) j) A_j: out[m'] = sum_m F[m'][m] P'_m,
-// F[m'][m] = 1/4 sum_j w_8^((2 m' + 1 - 2 m) j) (host: HalfGates::cross).  The forward transform applies s_(2m'+1)^e itself.
+// F[m'][m] = 1/4 sum_j w_8^((2 m' + 1 - 2 m) j) (host: CircuitState::half_cross, handle.hip).  The forward transform applies s_(2m'+1)^e itself.
 struct CrossMat {
   gl_t f[4][4];
 };

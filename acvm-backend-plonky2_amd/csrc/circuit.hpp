@@ -210,7 +210,8 @@ struct CircuitState {
   uint32_t half_slots = 0;        // number of such gates (0: none worth it)
   uint32_t gate_groups_half = 1;  // waves per row tile of the main kernel when those gates are looked up
   uint32_t sums_groups = 1;       // ... of gate_sums_kernel
-  int half_gates = 1;             // knob "half_gates"
+  int half_gates = 1;             // knob "half_gates": 0 never, 1 where it pays (half_auto), 2 always
+  bool half_auto = false;         // the circuit is large enough for the half-domain route to pay (handle.hip)
   gl_t half_cross[16];            // the even -> odd cross-coset matrix (gate_sums_cross_kernel)
   DBuf<gl_t> hsum, htmp_a, htmp_b;
   int device = 0;

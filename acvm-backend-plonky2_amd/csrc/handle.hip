@@ -335,13 +335,17 @@ static int circuit_create_one(const uint8_t *blob, size_t len, int device, p2gpu
     // Gates of degree <= 4 with enough constraints to pay for two transforms per challenge: evaluated on the even cosets only
     // (plonk.hip gate_sums_kernel).  The degree is the library's own count (gate_degree), not the blob's field.
     const char *he = getenv("P2GPU_HALF_GATES");  // 0: off (A/B measurements); the knob "half_gates" does the same per handle
-    uint32_t half_cost = 0;
-    if (!(he && *he == '0') && c->d >= 10 && c->rate_bits == 3)
+    uint64_t half_constraints = 0;
+    if (!(he && *he == '0') && c->d >= 6 && c->rate_bits == 3)
       for (auto &g : c->gates)
         if (g.kind != G_POSEIDON && g.num_constraints >= 48 && gate_degree(g.kind, g.p) <= 4 && c->half_slots < 64) {
           g.pad |= (++c->half_slots) << 16;
-          half_cost += cost(g);
+          half_constraints += g.num_constraints;
         }
+    // Worth it by default only where it saves more than its five extra launches cost a lone proof: ~77 lane-instructions per
+    // constraint on 4n rows at 37.7 T/s against ~100 us -- constraints x n >= 12 M (the heavy mix: from 2^14 gates on).  The knob
+    // "half_gates" = 2 takes the route whatever the size (tests).
+    c->half_auto = (half_constraints << c->d) >= ((uint64_t)12 << 20);
     if (c->half_slots) {
       // the main kernel without them: a look-up and two products per gate and challenge
       auto cost_main = [&](const GateDesc &g) { return gate_half_slot(g) ? 8u : cost(g); };

@@ -570,7 +570,8 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     q.gate_groups_half = c->gate_groups_half;
     q.nsk = c->half_slots * K;
     q.hsum = c->hsum.p;
-    q.use_half = c->half_gates && c->half_slots && c->wires.ncl == C && c->wires.cm.stride == 1 && c->wires.cm.first == 0;
+    q.use_half = (c->half_gates == 2 || (c->half_gates == 1 && c->half_auto)) && c->half_slots && c->wires.ncl == C && c->wires.cm.stride == 1 &&
+                 c->wires.cm.first == 0;
     if (q.use_half) {
       const size_t per = (size_t)4 * q.nsk * n;
       gate_sums_eval(st, q, n >= 64 ? c->sums_groups : 1u);

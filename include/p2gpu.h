@@ -224,9 +224,9 @@ int p2gpu_verify_compressed(const p2gpu_circuit *c, const uint8_t *cproof, size_
  * LDE(unit column); the proof bytes do not depend on it), "blocking_sync" (0/1, default 0: at the eleven transcript sync
  * points of a proof the calling thread spins in hipStreamSynchronize -- lowest latency; 1 = it sleeps on a blocking event,
  * ~10-30 us later per sync but without burning a CPU per proof in flight: for hosts with fewer CPUs than proving threads),
- * "half_gates" (0/1, default 1: the folded constraint sums of gates of degree <= 4 -- the reference's five custom gates,
- * BaseSum<4> -- are evaluated on the four even LDE cosets and interpolated to the odd ones; exact, the proof bytes do not
- * depend on it), "shard_intt" (0/1, default 0; sharded proofs only: every rank runs the inverse transforms of ITS block of
+ * "half_gates" (0/1/2, default 1: the folded constraint sums of gates of degree <= 4 -- the reference's five custom gates,
+ * BaseSum<4> -- are evaluated on the four even LDE cosets and interpolated to the odd ones where the circuit is large enough
+ * for that to pay (constraints x gates >= 12 M); 2 = whatever the size, 0 = never; exact, the proof bytes do not depend on it), "shard_intt" (0/1, default 0; sharded proofs only: every rank runs the inverse transforms of ITS block of
  * the dense wire / Z-partial-product columns and the coefficient blocks are all-gathered in place, instead of every rank
  * transforming every column -- SURVEY 8(e) steps 1-2; the proof bytes do not depend on it; every rank must set it alike) */
 int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value);

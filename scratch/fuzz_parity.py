@@ -39,7 +39,7 @@ for it in range(N):
         cd.set("self_check", 0 if mutated else 1)
         cd.set("zero_columns", int(rng.integers(0, 4) != 0))
         cd.set("virtual_columns", int(rng.integers(0, 3) != 0))
-        cd.set("half_gates", int(rng.integers(0, 3) != 0))   # round 6: gates of degree <= 4 on the even cosets only (d >= 10)
+        cd.set("half_gates", int(rng.integers(0, 3)))   # round 6: gates of degree <= 4 on the even cosets only (0 never, 1 where it pays, 2 always)
         expect, _ = oc.prove(w, public_inputs=pis)
         got = {"host": cd.prove(w, public_inputs=pis).to_bytes(),
                "dev": cd.prove(torch.from_numpy(w.view(np.int64)).cuda(), public_inputs=pis).to_bytes()}

@@ -1103,14 +1103,21 @@ def test_half_domain_gates_keep_every_byte(pkg, orc, gpu, d, mix, npi, W):
     cd.set("profile", 2)
     assert cd.prove(wires, public_inputs=pis).to_bytes() == want
     ran = any(k.startswith("gate_sums_kernel") for k in cd.kernel_stats())
-    assert ran == (mix == "ecdsa"), "the half-domain path runs exactly where a gate of degree <= 4 has >= 48 constraints"
+    # default (1): only where it pays -- constraints of such gates x gates >= 12 M: the heavy mix from 2^14 gates on
+    assert ran == (mix == "ecdsa" and d >= 15), "default: the half-domain path runs only on circuits large enough for it to pay"
+    cd.set("profile", 0)
+    cd.set("half_gates", 2)     # whatever the size
+    cd.set("profile", 2)
+    assert cd.prove(wires, public_inputs=pis).to_bytes() == want
+    ran = any(k.startswith("gate_sums_kernel") for k in cd.kernel_stats())
+    assert ran == (mix == "ecdsa"), "forced: the half-domain path runs exactly where a gate of degree <= 4 has >= 48 constraints"
     cd.set("profile", 0)
     cd.set("half_gates", 0)
     cd.set("profile", 2)
     assert cd.prove(wires, public_inputs=pis).to_bytes() == want
     assert not any(k.startswith("gate_sums_kernel") for k in cd.kernel_stats())
     cd.set("profile", 0)
-    cd.set("half_gates", 1)
+    cd.set("half_gates", 2)
     # a witness that breaks a range-checked limb of a half-domain gate: the identity fails at zeta whichever way the sums were made
     import torch
     bad = wires.copy()
@@ -1191,7 +1198,7 @@ def test_seeded_differential_fuzz(pkg, orc, gpu):
                 cd.set("self_check", 0 if mutated else 1)
                 cd.set("zero_columns", int(rng.integers(0, 4) != 0))
                 cd.set("virtual_columns", int(rng.integers(0, 3) != 0))
-                cd.set("half_gates", int(rng.integers(0, 3) != 0))
+                cd.set("half_gates", int(rng.integers(0, 3)))      # 0 never / 1 where it pays / 2 always
                 expect, _ = oc.prove(w, public_inputs=pis)
                 tag = (it, rnd, d, mix, seed, npi, nw, routed_only)
                 assert cd.prove(w, public_inputs=pis).to_bytes() == expect, ("host",) + tag

@@ -143,6 +143,27 @@ def test_poseidon_constants_and_vectors(orc):
         assert [int(x) for x in st] == v["output"]
 
 
+def test_poseidon_fused_layers_on_the_host(tmp_path):
+    """Round 6: the device runs the partial rounds' linear layers three at a time on products of the small-integer MDS matrix
+    (csrc/poseidon.hpp POSEIDON_FUSED: M, M P M, M P M P M; the PoseidonGate evaluator takes the same route).  The PRODUCT's header,
+    compiled for the host with g++: the permutation in that form -- integer row sums over the 32-bit halves, one reduction per row,
+    the poseidon_device_constants form of the round constants -- equals the plain form on plonky2's vectors, on 20 000 random and
+    extreme states, and no half-row sum leaves 58 bits.  (The GPU suite then checks the device code itself against the oracle.)"""
+    import subprocess
+
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "acvm-backend-plonky2_amd", "csrc", "tests", "poseidon_fused_selftest.cpp")
+    exe = str(tmp_path / "poseidon_fused_selftest")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src], check=True, timeout=300)
+    with open(os.path.join(GOLDEN, "poseidon.json")) as f:
+        gold = json.load(f)
+    vecs = gold["permutation_vectors"]
+    r = subprocess.run([exe], input="".join(" ".join(str(x) for x in v["input"]) + "\n" for v in vecs), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-500:]
+    lines = r.stdout.strip().splitlines()
+    assert [[int(x) for x in ln.split()] for ln in lines[:len(vecs)]] == [v["output"] for v in vecs]
+    assert lines[-1].startswith("mismatches 0 ") and int(lines[-1].split()[-1]) <= 58
+
+
 def test_poseidon_hash_no_pad(orc):
     out = np.ones(4, dtype=np.uint64)
     orc.lib().orc_poseidon_hash_no_pad(None, 0, out.ctypes.data)

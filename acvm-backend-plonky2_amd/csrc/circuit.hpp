@@ -269,6 +269,7 @@ struct CircuitState {
   void *shard_ctx = nullptr;
   void *rccl_comm = nullptr;              // ncclComm_t: RCCL transport, collectives on `stream`
   int shard_exercise = 0;                 // run the exchange steps even with world = 1 (plumbing test)
+  int shard_reduce = 0;                   // knob: column-sharded FRI batch reduction + all-gather / sum of the partial sums
   int shard_intt = 0;                     // knob: column-sharded inverse transforms of the wires / Z-PP + all-gather of the coefficient
                                           // blocks instead of the replicated transform; same bytes either way
   DBuf<gl_t> xchg_recv;

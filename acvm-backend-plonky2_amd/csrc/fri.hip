@@ -312,6 +312,19 @@ void reduce_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t 
                        accumulate ? 1 : 0, nzlist, basis, fold);
 }
 
+// out[p] = sum_q parts[q][p] (p < len): the partial sums of a column-sharded batch reduction, one part per rank
+__global__ __launch_bounds__(256) void sum_parts_kernel(const gl_t *__restrict__ parts, uint32_t nparts, size_t len, gl_t *__restrict__ out) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= len) return;
+  gl_t a = parts[p];
+  for (uint32_t q = 1; q < nparts; q++) a = gl_add(a, parts[(size_t)q * len + p]);
+  out[p] = a;
+}
+void sum_parts(hipStream_t st, const gl_t *parts, uint32_t nparts, size_t len, gl_t *out) {
+  ProfScope ps("sum_parts_kernel", 8.0 * (nparts + 1.0) * (double)len);
+  hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, parts, nparts, len, out);
+}
+
 __global__ __launch_bounds__(256) void fri_quotient_values_kernel(const gl_t *F0, const gl_t *F1, uint32_t d,
                                                                   const gl_t *tw, uint32_t tw_shift, ext_t zeta,
                                                                   ext_t gzeta, ext_t f0z, ext_t f1z, ext_t aK,

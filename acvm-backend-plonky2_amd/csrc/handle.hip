@@ -651,6 +651,7 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
   else if (k == "self_check") c->self_check = (int)value;
   else if (k == "shard_exercise") c->shard_exercise = (int)value;
   else if (k == "shard_intt") c->shard_intt = (int)value;
+  else if (k == "shard_reduce") c->shard_reduce = (int)value;
   else if (k == "half_gates") c->half_gates = (int)value;
   else if (k == "blocking_sync") c->blocking_sync = (int)value;
   else if (k == "virtual_columns") {

@@ -225,6 +225,8 @@ void reduce_columns(hipStream_t st, const gl_t *coeffs, uint32_t cols, uint32_t 
 // nzlist: list[0] = count, list[1..] = indices of the dense (class 2) columns; fold[2]: the class 1 columns' joint
 // coefficient of the unit column's polynomial `basis` in the reduction
 void compact_nonzero(hipStream_t st, const uint32_t *flags, uint32_t cols, uint32_t *list);
+// out[p] = sum_q parts[q * len + p]: the ranks' partial sums of a column-sharded batch reduction
+void sum_parts(hipStream_t st, const gl_t *parts, uint32_t nparts, size_t len, gl_t *out);
 void class1_fold(hipStream_t st, const ColHints &h, uint32_t cols, const gl_t *apow, uint32_t j0, gl_t *fold);
 // final[k] = aK * (F0[k] - f0z) / (x_k - zeta) + (F1[k] - f1z) / (x_k - gzeta), x_k = w_n^k
 void fri_quotient_values(hipStream_t st, const gl_t *F0, const gl_t *F1, uint32_t d, const gl_t *tw, uint32_t tw_shift,

@@ -712,7 +712,30 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     HIP_TRY(hipMemcpyAsync(c->ext_apow.p, apw, 16 * (size_t)nall, hipMemcpyHostToDevice, st));
     gl_t *F0 = c->f01.p, *F1 = c->f01.p + 2 * n;
     uint32_t j0 = 0;
-    for (int o = 0; o < 4; o++) {
+    bool reduced = false;
+    if (c->shard_reduce && sharded(c)) {
+      // SURVEY 8(e) step 8, the FRI batch reduction (knob "shard_reduce"): every rank holds every coefficient, so rank q sums only
+      // its block of the 354 concatenated columns (plain loop: structured columns' coefficients are in memory like anybody's) and
+      // the partial sums F0_q [2][n] are all-gathered and added -- field addition is exact, the sum does not depend on the split
+      const uint32_t G = (uint32_t)c->shard_world, cpr = (nall + G - 1) / G;
+      const uint32_t c0 = std::min(cpr * (uint32_t)c->shard_rank, nall), c1 = std::min(c0 + cpr, nall);
+      bool first = true;
+      uint32_t jo = 0;
+      for (int o = 0; o < 4; o++) {
+        const uint32_t co = oracles[o]->cols;
+        const uint32_t lo = std::max(c0, jo) - jo, hi = std::min(c1, jo + co) > jo ? std::min(c1, jo + co) - jo : 0;
+        if (hi > lo) {
+          reduce_columns(st, oracles[o]->coeffs.p + (size_t)lo * n, hi - lo, d, c->ext_apow.p, jo + lo, F0, !first);
+          first = false;
+        }
+        jo += co;
+      }
+      if (first) HIP_TRY(hipMemsetAsync(F0, 0, 16 * n, st));
+      if (int rc = shard_allgather(c, F0, c->xchg_recv.p, 16 * n)) return rc;
+      sum_parts(st, c->xchg_recv.p, G, 2 * n, F0);
+      reduced = true;
+    }
+    for (int o = reduced ? 4 : 0; o < 4; o++) {
       const bool hw = batch_colnz(c, *oracles[o]) != nullptr;
       const bool unit = hw && c->sparse_coeffs.p != nullptr;
       if (unit) class1_fold(st, wire_hints(c, 0, false), c->W, c->ext_apow.p, j0, c->sparse_partial.p + 32);

@@ -125,7 +125,7 @@ def exchange_bytes(entry_bytes, world_size):
 
 def exchange_plan(degree_bits, world_size, num_wires=234, num_constants_sigmas=84, num_challenges=2, partial_products=9,
                   quotient_degree_factor=8, rate_bits=3, cap_height=4, num_queries=28, host_witness=False, dense_columns=None,
-                  shard_intt=False, dense_list=None):
+                  shard_intt=False, dense_list=None, shard_reduce=False):
     """The exchange steps of ONE coset-sharded proof (csrc/prover.hip shard_allgather call sites), in
     order: [(what, bytes each rank sends)].  Every step is an all-gather over the `world_size` ranks, so a rank receives
     (world_size - 1) x those bytes (a tuple: unequal blocks, bytes per rank -- `exchange_bytes`); nothing else crosses between the GPUs.  Host-side restatement for tests and budgets: the
@@ -164,6 +164,10 @@ def exchange_plan(degree_bits, world_size, num_wires=234, num_constants_sigmas=8
     plan.append(("quotient interpolants", K * cl * n * 8))
     plan.append(("quotient cap", cap_bytes))
     plan.append(("opening partial sums", -(-(nall + K) // G) * parts * 2 * 8))
+    if shard_reduce:
+        # SURVEY 8(e) step 8, second half: every rank batch-reduces only its block of the concatenated columns; the partial sums
+        # F0_q (an extension-field polynomial: 2 n words) are all-gathered and added
+        plan.append(("FRI batch-reduce partial sums", 16 * n))
     plan.append(("first FRI tree cap", cap_bytes))      # later FRI trees are small and built whole on every rank
     plan.append(("PoW minima", 8))                      # one per grinding batch; the first batch almost always holds a witness
     per_query = 0

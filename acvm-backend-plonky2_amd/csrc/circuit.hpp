@@ -252,7 +252,7 @@ struct CircuitState {
   gl_t poseidon_rc[360];
   gl_t poseidon_rc_gate[360];  // poseidon_device_constants(poseidon_rc): what eval_poseidon_gate takes
   // work buffers
-  DBuf<gl_t> wires_vals, zp_vals, cp, rowprod, scan_tmp, apow, qvals, qtmp, pw, partial, ext_apow, f01, f01v, fv;
+  DBuf<gl_t> wires_vals, zp_vals, cp, scan_tmp, apow, qvals, qtmp, pw, partial, ext_apow, f01, f01v, fv;
   std::vector<DBuf<gl_t>> fri_coef, fri_vals;
   std::vector<Batch> fri_trees;  // only dig/level_off/cap used
   DBuf<unsigned long long> pow_result;
@@ -269,6 +269,7 @@ struct CircuitState {
   void *shard_ctx = nullptr;
   void *rccl_comm = nullptr;              // ncclComm_t: RCCL transport, collectives on `stream`
   int shard_exercise = 0;                 // run the exchange steps even with world = 1 (plumbing test)
+  int shard_zs = 0;                       // knob: the chunk quotients of the permutation argument row-sharded + all-gather
   int shard_reduce = 0;                   // knob: column-sharded FRI batch reduction + all-gather / sum of the partial sums
   int shard_intt = 0;                     // knob: column-sharded inverse transforms of the wires / Z-PP + all-gather of the coefficient
                                           // blocks instead of the replicated transform; same bytes either way

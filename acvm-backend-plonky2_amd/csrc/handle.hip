@@ -13,7 +13,7 @@ void circuit_release(p2gpu_circuit *c) {
   c->d_row_gate.release(); c->d_gconsts.release(); c->d_prc.release(); c->d_prc_hash.release(); c->qconst.release();
   c->hsum.release(); c->htmp_a.release(); c->htmp_b.release();
   c->cs.release(); c->wires.release(); c->zp.release(); c->quot.release();
-  c->wires_vals.release(); c->zp_vals.release(); c->cp.release(); c->rowprod.release(); c->scan_tmp.release();
+  c->wires_vals.release(); c->zp_vals.release(); c->cp.release(); c->scan_tmp.release();
   c->apow.release(); c->qvals.release(); c->qtmp.release(); c->pw.release(); c->partial.release();
   c->ext_apow.release(); c->f01.release(); c->f01v.release(); c->fv.release();
   for (auto &b : c->fri_coef) b.release();
@@ -530,8 +530,7 @@ static int circuit_create_one(const uint8_t *blob, size_t len, int device, p2gpu
       ntt_batch(st, c->plan_fwd, c->sparse_coeffs.p + (size_t)s * n, c->sparse_lde.p + (size_t)s * C * n, 1, C, c->scale.p, 1, false);
   }
   CK(c->zp_vals.alloc((size_t)nzp * n), "alloc zp");
-  CK(c->cp.alloc((size_t)K * c->nchunks * n), "alloc cp");
-  CK(c->rowprod.alloc((size_t)K * n), "alloc rowprod");
+  CK(c->cp.alloc((size_t)K * (c->nchunks + 1) * n), "alloc cp");  // chunk quotients + the row products behind them (ZsArgs::cp)
   CK(c->scan_tmp.alloc((size_t)K * (n + (n + 255) / 256 + 8)), "alloc scan");
   CK(c->apow.alloc((size_t)2 * c->nterms), "alloc apow");
   CK(c->qvals.alloc((size_t)K * C * n), "alloc qvals");
@@ -652,6 +651,7 @@ int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value) try {
   else if (k == "shard_exercise") c->shard_exercise = (int)value;
   else if (k == "shard_intt") c->shard_intt = (int)value;
   else if (k == "shard_reduce") c->shard_reduce = (int)value;
+  else if (k == "shard_zs") c->shard_zs = (int)value;
   else if (k == "half_gates") c->half_gates = (int)value;
   else if (k == "blocking_sync") c->blocking_sync = (int)value;
   else if (k == "virtual_columns") {

@@ -142,11 +142,17 @@ struct ZsArgs {
   uint32_t tw_shift;
   uint32_t d, R, QF, nchunks, K;
   gl_t betas[MAX_CHALLENGES], gammas[MAX_CHALLENGES];
-  gl_t *cp;      // [K][nchunks][n] chunk quotients (scratch)
-  gl_t *rowprod; // [K][n]
+  gl_t *cp;      // chunk quotients (scratch) + the row products behind them: K * (nchunks + 1) columns, column K * nchunks + c =
+                 // the row products of challenge c.  Layout [n >> sb][columns][1 << sb] (zs_idx): sb = d is the plain [columns][n];
+                 // a rank of a row-sharded computation (knob shard_zs) writes its rows as ONE contiguous block, sb = d - log2(ranks)
+  uint32_t sb;   // slice bits of that layout
+  uint32_t row0, rows;  // the rows this launch of the chunk kernel computes (all: 0, n)
   gl_t *zp;      // out [K*(1+PP)][n]
 };
 void zs_partial_products(hipStream_t st, const ZsArgs &a, gl_t *scan_tmp);
+// the two halves of it: chunk quotients + row products of rows [a.row0, a.row0 + a.rows) | scan + Z / partial products of all rows
+void zs_chunks(hipStream_t st, const ZsArgs &a);
+void zs_scan_finish(hipStream_t st, const ZsArgs &a, gl_t *scan_tmp);
 
 struct QuotArgs {
   const gl_t *cs_lde;    // [cosets][NC+R][n]

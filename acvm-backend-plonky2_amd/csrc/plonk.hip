@@ -43,11 +43,16 @@ __device__ __forceinline__ gl_t root_pow(const gl_t *tw, uint32_t shift, uint32_
 }
 
 // ---- Z / partial products -------------------------------------------------------
+// position of (column, row i) in the chunk-quotient scratch (ZsArgs::cp): [i >> sb][column][i & (2^sb - 1)]
+__device__ __forceinline__ size_t zs_idx(const ZsArgs &a, uint32_t col, uint32_t i) {
+  const uint32_t cols = a.K * (a.nchunks + 1);
+  return ((((size_t)(i >> a.sb) * cols + col) << a.sb) | (i & ((1u << a.sb) - 1u)));
+}
 __global__ __launch_bounds__(256) void zs_chunk_kernel(ZsArgs a) {
   const uint32_t n = 1u << a.d;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t c = blockIdx.y;
-  if (i >= n) return;
+  if (i >= a.row0 + a.rows) return;
   const gl_t x = root_pow(a.sub_tw, a.tw_shift, a.d, i);
   const gl_t beta = a.betas[c], gamma = a.gammas[c];
   const gl_t bx = gl_mul(beta, x);
@@ -79,10 +84,10 @@ __global__ __launch_bounds__(256) void zs_chunk_kernel(ZsArgs a) {
     gl_t di = gl_mul(inv, pre[m]);
     inv = gl_mul(inv, dp[m]);
     gl_t q = gl_mul(np[m], di);
-    a.cp[((size_t)c * a.nchunks + m) * n + i] = q;
+    a.cp[zs_idx(a, c * a.nchunks + m, i)] = q;
     rowp = gl_mul(rowp, q);
   }
-  a.rowprod[(size_t)c * n + i] = rowp;
+  a.cp[zs_idx(a, a.K * a.nchunks + c, i)] = rowp;
 }
 
 // exclusive multiplicative scan across a block (blockDim <= 1024)
@@ -104,12 +109,11 @@ __device__ __forceinline__ gl_t block_scan_mul(gl_t v, gl_t *lds, gl_t *total) {
   return excl;
 }
 
-__global__ __launch_bounds__(256) void scan_local_kernel(const gl_t *rowprod, uint32_t n, gl_t *local, gl_t *bsum,
-                                                         uint32_t nblocks) {
+__global__ __launch_bounds__(256) void scan_local_kernel(const ZsArgs a, uint32_t n, gl_t *local, gl_t *bsum, uint32_t nblocks) {
   __shared__ gl_t lds[256];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t c = blockIdx.y;
-  gl_t v = i < n ? rowprod[(size_t)c * n + i] : 1;
+  gl_t v = i < n ? a.cp[zs_idx(a, a.K * a.nchunks + c, i)] : 1;
   gl_t total;
   gl_t excl = block_scan_mul(v, lds, &total);
   if (i < n) local[(size_t)c * n + i] = excl;
@@ -143,26 +147,32 @@ __global__ __launch_bounds__(256) void zs_finish_kernel(ZsArgs a, const gl_t *lo
   a.zp[(size_t)c * n + i] = z;
   gl_t acc = z;
   for (uint32_t m = 0; m < PP; m++) {
-    acc = gl_mul(acc, a.cp[((size_t)c * a.nchunks + m) * n + i]);
+    acc = gl_mul(acc, a.cp[zs_idx(a, c * a.nchunks + m, i)]);
     a.zp[((size_t)a.K + (size_t)c * PP + m) * n + i] = acc;
   }
 }
 
-// scan_tmp: at least K * (n + ceil(n/256)) elements
-void zs_partial_products(hipStream_t st, const ZsArgs &a, gl_t *scan_tmp) {
+// chunk quotients and row products of the rows [a.row0, a.row0 + a.rows)
+void zs_chunks(hipStream_t st, const ZsArgs &a) {
+  if (!a.rows) return;
+  ProfScope ps("zs_chunk_kernel", 8.0 * a.K * (double)a.rows * (2.0 * a.R + a.nchunks + 1));
+  hipLaunchKernelGGL(zs_chunk_kernel, dim3((a.rows + 255) / 256, a.K), dim3(256), 0, st, a);
+}
+// multiplicative scan of the row products + Z and the partial products of every row; scan_tmp: at least K * (n + ceil(n/256)) elements
+void zs_scan_finish(hipStream_t st, const ZsArgs &a, gl_t *scan_tmp) {
   const uint32_t n = 1u << a.d;
   const uint32_t threads = 256;
   const uint32_t nblocks = (n + threads - 1) / threads;
   gl_t *local = scan_tmp;
   gl_t *bsum = scan_tmp + (size_t)a.K * n;
-  {
-  ProfScope ps("zs_chunk_kernel", 8.0 * a.K * (double)n * (2.0 * a.R + a.nchunks + 1));
-  hipLaunchKernelGGL(zs_chunk_kernel, dim3(nblocks, a.K), dim3(threads), 0, st, a);
-  }
   ProfScope ps2("zs_scan_finish", 8.0 * a.K * (double)n * (2.0 * a.nchunks + 4));
-  hipLaunchKernelGGL(scan_local_kernel, dim3(nblocks, a.K), dim3(threads), 0, st, a.rowprod, n, local, bsum, nblocks);
+  hipLaunchKernelGGL(scan_local_kernel, dim3(nblocks, a.K), dim3(threads), 0, st, a, n, local, bsum, nblocks);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(a.K), dim3(1024), 0, st, bsum, nblocks);
   hipLaunchKernelGGL(zs_finish_kernel, dim3(nblocks, a.K), dim3(threads), 0, st, a, local, bsum, nblocks);
+}
+void zs_partial_products(hipStream_t st, const ZsArgs &a, gl_t *scan_tmp) {
+  zs_chunks(st, a);
+  zs_scan_finish(st, a, scan_tmp);
 }
 
 // ---- gate constraints -------------------------------------------------------------

@@ -513,9 +513,26 @@ int prove_impl(p2gpu_circuit *c, const gl_t *wires_dev, const uint64_t *pis, uin
     a.d = d; a.R = R; a.QF = QF; a.nchunks = c->nchunks; a.K = K;
     for (uint32_t k = 0; k < 2; k++) { a.betas[k] = betas[k]; a.gammas[k] = gammas[k]; }
     a.cp = c->cp.p;
-    a.rowprod = c->rowprod.p;
     a.zp = c->zp_vals.p;
-    zs_partial_products(st, a, c->scan_tmp.p);
+    a.sb = d;
+    a.row0 = 0;
+    a.rows = (uint32_t)n;
+    uint32_t lgG = 0;
+    while ((1u << lgG) < (uint32_t)c->shard_world) lgG++;
+    if (c->shard_zs && sharded(c) && (1u << lgG) == (uint32_t)c->shard_world && d >= lgG) {
+      // SURVEY 8(e) step 5 (knob "shard_zs"): the expensive half -- 160 factors, the batch inversion and the chunk quotients of every
+      // row -- split by rows; rank q writes its n / G rows as one contiguous block of the scratch ([rank][column][n / G], zs_idx) and
+      // the blocks are all-gathered in place.  The scan and the products along the chunks then run on every rank (two cheap passes).
+      a.sb = d - lgG;
+      a.rows = (uint32_t)(n >> lgG);
+      a.row0 = a.rows * (uint32_t)c->shard_rank;
+      zs_chunks(st, a);
+      const size_t blk = (size_t)K * (c->nchunks + 1) * a.rows;
+      if (int rc = shard_allgather(c, c->cp.p + blk * (size_t)c->shard_rank, c->cp.p, blk * sizeof(gl_t))) return rc;
+      zs_scan_finish(st, a, c->scan_tmp.p);
+    } else {
+      zs_partial_products(st, a, c->scan_tmp.p);
+    }
   }
   TRACE(c, "zs_partial_products");
   if (int rc = batch_commit_from_values(c, c->zp, c->zp_vals.p)) return rc;

@@ -125,7 +125,7 @@ def exchange_bytes(entry_bytes, world_size):
 
 def exchange_plan(degree_bits, world_size, num_wires=234, num_constants_sigmas=84, num_challenges=2, partial_products=9,
                   quotient_degree_factor=8, rate_bits=3, cap_height=4, num_queries=28, host_witness=False, dense_columns=None,
-                  shard_intt=False, dense_list=None, shard_reduce=False):
+                  shard_intt=False, dense_list=None, shard_reduce=False, shard_zs=False, num_routed=80):
     """The exchange steps of ONE coset-sharded proof (csrc/prover.hip shard_allgather call sites), in
     order: [(what, bytes each rank sends)].  Every step is an all-gather over the `world_size` ranks, so a rank receives
     (world_size - 1) x those bytes (a tuple: unequal blocks, bytes per rank -- `exchange_bytes`); nothing else crosses between the GPUs.  Host-side restatement for tests and budgets: the
@@ -158,6 +158,11 @@ def exchange_plan(degree_bits, world_size, num_wires=234, num_constants_sigmas=8
         dl = list(dense_list) if dense_list is not None else list(range(num_wires if dense_columns is None else dense_columns))
         plan.append(("wires coefficient blocks", tuple(8 * (hi - lo) * n for lo, hi in intt_blocks(dl, G))))
     plan.append(("wires cap", cap_bytes))
+    if shard_zs:
+        # the chunk quotients of the permutation argument (and the row products behind them) are computed
+        # for n / G rows per rank and all-gathered in place; the scan runs on every rank
+        nchunks = -(-num_routed // quotient_degree_factor)
+        plan.append(("Z chunk quotient blocks", 8 * K * (nchunks + 1) * (n // G)))
     if shard_intt:
         plan.append(("Z / partial products coefficient blocks", tuple(8 * (hi - lo) * n for lo, hi in intt_blocks(range(nzp), G))))
     plan.append(("Z / partial products cap", cap_bytes))

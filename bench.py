@@ -276,7 +276,8 @@ def compact_line(out, detail_name="bench_detail.json"):
     for k in ("latency_ms_single_proof", "latency_ms_single_proof_host_witness", "value_host_witness", "cold_process_ms"):
         line[k] = out.get(k)
     if (out.get("n_gpus") or 1) > 1 or out.get("peer_access") is not None:
-        for k in ("latency_ms_sharded", "latency_ms_sharded_intt", "latency_ms_sharded_group", "latency_ms_sharded_group_intt", "rccl_ranks", "peer_access",
+        for k in ("latency_ms_sharded", "latency_ms_sharded_intt", "latency_ms_sharded_all_steps", "latency_ms_sharded_group", "latency_ms_sharded_group_intt",
+                  "latency_ms_sharded_group_all_steps", "rccl_ranks", "peer_access",
                   "ranks_share_devices"):
             line[k] = out.get(k)
         sh = out.get("sharded") or {}
@@ -471,7 +472,7 @@ def group_probe(pkg, args, group, blob, wires, pis):
         cd.prove(wd, public_inputs=pis)
     ms = (time.perf_counter() - t0) / k * 1e3
     # knob shard_intt: column-sharded inverse transforms + all-gather of the coefficient blocks (peer copies, in place)
-    ms_intt, same = None, None
+    ms_intt, ms_all, same = None, None, None
     try:
         cd.set("shard_intt", 1)
         same = cd.prove(wd, public_inputs=pis).to_bytes() == ref.to_bytes()
@@ -480,15 +481,24 @@ def group_probe(pkg, args, group, blob, wires, pis):
         for _ in range(k):
             cd.prove(wd, public_inputs=pis)
         ms_intt = (time.perf_counter() - t0) / k * 1e3
+        cd.set("shard_zs", 1)        # every step of SURVEY 8(e)'s table sharded
+        cd.set("shard_reduce", 1)
+        same = same and cd.prove(wd, public_inputs=pis).to_bytes() == ref.to_bytes()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            cd.prove(wd, public_inputs=pis)
+        ms_all = (time.perf_counter() - t0) / k * 1e3
     except Exception as e:
         same = repr(e)[:200]
-    cd.set("shard_intt", 0)
+    for k_ in ("shard_intt", "shard_zs", "shard_reduce"):
+        cd.set(k_, 0)
     cd.set("profile", 2)
     for _ in range(2):
         cd.prove(wd, public_inputs=pis)
     st = cd.kernel_stats()
     cd.set("profile", 0)
-    out = {"devices": group, "latency_ms_sharded_group": ms, "latency_ms_sharded_group_intt": ms_intt, "shard_intt_same_bytes": same,
+    out = {"devices": group, "latency_ms_sharded_group": ms, "latency_ms_sharded_group_intt": ms_intt, "latency_ms_sharded_group_all_steps": ms_all, "shard_intt_same_bytes": same,
            "proofs": k, "peer_access": pkg.peer_access(),
            "exchanges": exchange_stats(st, 2), "proof_bytes": len(ref),
            "transport": "hipMemcpyPeerAsync between the ranks' streams, one host thread per rank inside p2gpu_prove_dev"}
@@ -1039,7 +1049,20 @@ def main():
                     csh.prove(w1, public_inputs=pis1)
                 sharded_half_["exchanges_rank0_shard_intt"] = exchange_stats(csh.kernel_stats(), 2)
                 csh.set("profile", 0)
-                csh.set("shard_intt", 0)
+                # ... and with every step of SURVEY 8(e)'s table sharded: + the permutation argument's chunk quotients by rows (shard_zs),
+                # + the FRI batch reduction by columns (shard_reduce)
+                csh.set("shard_zs", 1)
+                csh.set("shard_reduce", 1)
+                pr3 = csh.prove(w1, public_inputs=pis1)
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.sharded_steps):
+                    pr3 = csh.prove(w1, public_inputs=pis1)
+                barrier()
+                sharded_half_["latency_ms_sharded_all_steps"] = pkg.parallel.max_over_ranks(time.perf_counter() - t1) / args.sharded_steps * 1e3
+                sharded_half_["all_steps_same_bytes"] = pr3.to_bytes() == pr1.to_bytes()
+                for k_ in ("shard_intt", "shard_zs", "shard_reduce"):
+                    csh.set(k_, 0)
                 barrier()
             except Exception as e:   # (a library error is raised on every rank alike: the ranks stay in step)
                 sharded_half_["shard_intt_error"] = repr(e)[:300]
@@ -1198,6 +1221,8 @@ def main():
             "latency_ms_sharded_group": (sharded_half.get("group") or {}).get("latency_ms_sharded_group") if sharded_half else None,
             "latency_ms_sharded_intt": sharded_half.get("latency_ms_sharded_intt") if sharded_half else None,
             "latency_ms_sharded_group_intt": (sharded_half.get("group") or {}).get("latency_ms_sharded_group_intt") if sharded_half else None,
+            "latency_ms_sharded_all_steps": sharded_half.get("latency_ms_sharded_all_steps") if sharded_half else None,
+            "latency_ms_sharded_group_all_steps": (sharded_half.get("group") or {}).get("latency_ms_sharded_group_all_steps") if sharded_half else None,
             "rccl_ranks": sharded_half["rccl_ranks"] if sharded_half else (world if sharded and args.backend == "nccl" else 0),
             "peer_access": (sharded_half.get("group") or {}).get("peer_access") if sharded_half else (pkg.peer_access() if group else None),
             "sharded": sharded_half,

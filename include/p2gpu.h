@@ -228,7 +228,11 @@ int p2gpu_verify_compressed(const p2gpu_circuit *c, const uint8_t *cproof, size_
  * BaseSum<4> -- are evaluated on the four even LDE cosets and interpolated to the odd ones where the circuit is large enough
  * for that to pay (constraints x gates >= 12 M); 2 = whatever the size, 0 = never; exact, the proof bytes do not depend on it), "shard_intt" (0/1, default 0; sharded proofs only: every rank runs the inverse transforms of ITS block of
  * the dense wire / Z-partial-product columns and the coefficient blocks are all-gathered in place, instead of every rank
- * transforming every column -- SURVEY 8(e) steps 1-2; the proof bytes do not depend on it; every rank must set it alike) */
+ * transforming every column -- SURVEY 8(e) steps 1-2; the proof bytes do not depend on it; every rank must set it alike),
+ * "shard_zs" (0/1, default 0; sharded proofs only: the chunk quotients of the permutation argument are computed for n / ranks rows
+ * per rank and all-gathered in place -- SURVEY 8(e) step 5), "shard_reduce" (0/1, default 0; sharded proofs only: every rank
+ * batch-reduces only its block of the opened polynomials for FRI, the partial sums are all-gathered and added -- step 8); same
+ * rules: no proof byte depends on them, every rank sets them alike */
 int p2gpu_circuit_set(p2gpu_circuit *c, const char *key, uint64_t value);
 /* statistics accumulated while "profile" = 1, one entry per kernel symbol:
  * names[64*i] (NUL-terminated), total milliseconds, total algorithmic bytes,

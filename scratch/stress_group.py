@@ -27,6 +27,7 @@ def work(i, n):
         if it % 7 == 0:
             cd.set("shard_intt", (it // 7) % 2)   # round 6: column-sharded inverse transforms + in-place all-gather of the blocks, on and off
             cd.set("shard_reduce", (it // 14) % 2)   # ... and the column-sharded FRI batch reduction
+            cd.set("shard_zs", (it // 7 + it // 14) % 2)   # ... and the row-sharded chunk quotients of the permutation argument
         if it % 5 == 3:
             p = cd.prove_routed(np.ascontiguousarray(wh[:80]), public_inputs=pis).to_bytes()
         else:

@@ -186,6 +186,9 @@ def test_exchange_plan_of_a_sharded_proof(pkg, d, world):
     assert par.exchange_bytes(wb, G) == (max(wb), sum(wb)) and par.exchange_bytes(64, G) == (64, 64 * G)
     assert par.intt_blocks([], 4) == [(0, 0)] * 4 and par.intt_blocks([5], 2) == [(0, 0), (5, 6)]
     assert par.exchange_budget(sp, world) > par.exchange_budget(plan, world)
+    # knob shard_zs: the chunk quotients of the permutation argument by rows, 2 x (10 + 1) columns of n / G rows per rank
+    zp_ = par.exchange_plan(d, world, shard_zs=True)
+    assert [p[0] for p in zp_] == names[:1] + ["Z chunk quotient blocks"] + names[1:] and dict(zp_)["Z chunk quotient blocks"] == 8 * 22 * (n // G)
     # knob shard_reduce: one more exchange, the partial sums of the column-sharded FRI batch reduction
     rp = par.exchange_plan(d, world, shard_reduce=True)
     assert [p[0] for p in rp] == names[:5] + ["FRI batch-reduce partial sums"] + names[5:] and dict(rp)["FRI batch-reduce partial sums"] == 16 * n

@@ -641,10 +641,12 @@ def _shard_worker(rank, world, port, d, mix, npi, q):
     # knob shard_intt: the inverse transforms of the wires / Z-PP columns replicated (0) or column-sharded with an all-gather of
     # the coefficient blocks (1) -- the same bytes either way, through every entry point, and with the column classes off
     # ... and knob shard_reduce: the FRI batch reduction replicated (0) or column-sharded with an all-gather + sum of the partial sums (1)
-    for intt, zc, red in ((0, 1, 0), (1, 1, 1), (1, 0, 0), (0, 1, 1)):
+    # ... and knob shard_zs: the chunk quotients of the permutation argument on every rank (0) or row-sharded + all-gathered in place (1)
+    for intt, zc, red, zs in ((0, 1, 0, 0), (1, 1, 1, 1), (1, 0, 0, 1), (0, 1, 1, 0)):
         cd.set("shard_intt", intt)
         cd.set("zero_columns", zc)
         cd.set("shard_reduce", red)
+        cd.set("shard_zs", zs)
         got = [cd.prove(wires, public_inputs=pis).to_bytes(), cd.prove(wd, public_inputs=pis).to_bytes(), cd.prove(own, public_inputs=pis).to_bytes()]
         p1 = p1 or got[0]
         same = same and got == [p1] * 3
@@ -775,6 +777,7 @@ def test_rccl_transport_single_rank(pkg, orc, gpu, d, mix, npi):
     cd.set("shard_exercise", 1)
     got = cd.prove(wires, public_inputs=pis).to_bytes()
     assert got == plain == orc.OracleCircuit(blob).prove(wires, public_inputs=pis)[0]
+    cd.set("shard_zs", 1)       # one rank computes every row's chunk quotients; the (one-block) all-gather is in place
     cd.set("shard_reduce", 1)   # one rank sums every column; its "partial" sum goes through the all-gather and the adding kernel
     assert cd.prove(wires, public_inputs=pis).to_bytes() == plain
     cd.set("shard_intt", 1)     # one rank owns every block: the transform runs block-wise; the exchange has no peer, but the grouped
@@ -782,6 +785,7 @@ def test_rccl_transport_single_rank(pkg, orc, gpu, d, mix, npi):
     assert cd.prove(wires, public_inputs=pis).to_bytes() == plain
     cd.set("shard_intt", 0)
     cd.set("shard_reduce", 0)
+    cd.set("shard_zs", 0)
     cd.set("shard_exercise", 0)
     assert cd.prove(wires, public_inputs=pis).to_bytes() == plain
     cd.close()
@@ -953,12 +957,13 @@ def test_exchange_plan_matches_the_library(pkg, gpu, world):
         single = [int(r[0]) for r in nzrows if len(r) == 1]
         pi_row = max(set(single), key=single.count) if single else -1
         dense_list = [j for j, r in enumerate(nzrows) if len(r) > 1 or (len(r) == 1 and int(r[0]) != pi_row)]
-        for host, w, ncols, intt, red in ((False, wd, None, 0, 0), (True, wires, None, 0, 1), (False, wd, None, 1, 1), (True, wires, None, 1, 0)):
+        for host, w, ncols, intt, red, zs in ((False, wd, None, 0, 0, 0), (True, wires, None, 0, 1, 1), (False, wd, None, 1, 1, 0), (True, wires, None, 1, 0, 1)):
             cd.set("shard_intt", intt)
             cd.set("shard_reduce", red)
+            cd.set("shard_zs", zs)
             plan = pkg.parallel.exchange_plan(d, world, num_wires=int(hdr[3]), num_constants_sigmas=int(hdr[5]) + int(hdr[4]), host_witness=host,
-                                              dense_columns=ncols, shard_intt=bool(intt), dense_list=dense_list, shard_reduce=bool(red))
-            assert len(plan) == 8 + int(host) + 2 * intt + red
+                                              dense_columns=ncols, shard_intt=bool(intt), dense_list=dense_list, shard_reduce=bool(red), shard_zs=bool(zs))
+            assert len(plan) == 8 + int(host) + 2 * intt + red + zs
             want = classes(plan)
             cd.prove(w)
             cd.set("profile", 2)
@@ -1012,6 +1017,7 @@ def test_single_process_device_group(pkg, orc, gpu, world):
             # column-sharded inverse transforms: the coefficient blocks go rank to rank as peer copies, in place
             cd.set("shard_intt", 1)
             cd.set("shard_reduce", 1)   # ... and the FRI batch reduction column-sharded, partial sums all-gathered and added
+            cd.set("shard_zs", 1)       # ... and the permutation argument's chunk quotients row-sharded, blocks all-gathered in place
             assert cd.prove(wires, public_inputs=pis).to_bytes() == want
             assert cd.prove(wd, public_inputs=pis).to_bytes() == want
             assert cd.prove_routed(np.ascontiguousarray(wires[:80]), public_inputs=pis).to_bytes() == want
@@ -1020,6 +1026,7 @@ def test_single_process_device_group(pkg, orc, gpu, world):
             cd.set("zero_columns", 1)
             cd.set("shard_intt", 0)
             cd.set("shard_reduce", 0)
+            cd.set("shard_zs", 0)
             # an unsatisfied witness fails on every rank at the same point; the group is usable afterwards
             bad = wires.copy()
             bad[0, 1] = (int(bad[0, 1]) + 1) % P

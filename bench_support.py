@@ -1,6 +1,6 @@
 """bench_support.py -- what bench.py's measurement rests on, apart from the run itself: SURVEY 8(d)'s byte counts per prover step, the look-up
 of the committed counter summaries (profiles/rNN_<mix><d>_{pmc,sq}_summary.json) behind `roofline.traffic` / `valu_issue` / `valu_floor`, the
-ONE stdout line (`compact_line`), the CPU baseline legs (the oracle: test infrastructure, timed, never the product), the rank launcher of
+ONE stdout line (`compact_line`), the rank launcher of
 `--gpus N`, the device-group probe and the cold-process measurement.  bench.py keeps the run: warm-up, timed region, passes, result."""
 import glob
 import json
@@ -294,57 +294,6 @@ def effective_cores():
     except Exception:
         pass
     return n
-
-
-def _oracle_leg(d, mix, n_pi, threads, timeout=900):
-    """One oracle proof of synth(d, mix) in a fresh process with OMP_NUM_THREADS=threads -> (seconds, phase seconds)."""
-    import subprocess
-    code = ("import sys,time,json;sys.path.insert(0,%r);import __graft_entry__ as e;p=e.load_package();o=e.load_oracle();"
-            "m=p.make_circuit(%d,%r,seed=1,num_public_inputs=%d);c=o.OracleCircuit(m[0]);t=time.perf_counter();"
-            "pr,tr=c.prove(m[1],public_inputs=(m[2] if %d else ()));dt=time.perf_counter()-t;"
-            "print(json.dumps([dt,tr.t_wires,tr.t_zs,tr.t_quotient,tr.t_openings,tr.t_fri,o.lib().orc_num_threads()]))"
-            % (ROOT, d, mix, n_pi, n_pi))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout,
-                       env=dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false"))
-    v = json.loads(r.stdout.strip().splitlines()[-1])
-    return v[0], dict(zip(["wires", "zs", "quotient", "openings", "fri"], v[1:6])), int(v[6])
-
-
-def cpu_baseline(pkg, d, mix, n_pi, single_thread_bits):
-    """The oracle (CPU port of the same path, oracle/) on the SAME circuit the GPU was timed on, on the host CPUs this
-    process may use (cgroup quota, see effective_cores), one full proof, no scaling; plus a one-thread leg on a bounded
-    smaller sample (a full one-thread proof at 2^20 rows takes ~40 s).  Test infrastructure, timed as a baseline --
-    never the target."""
-    import subprocess
-    cores = effective_cores()
-    try:
-        cpu = subprocess.run(["sh", "-c", "grep -m1 'model name' /proc/cpuinfo | cut -d: -f2"], capture_output=True, text=True).stdout.strip()
-    except Exception:
-        cpu = ""
-    try:
-        dt, phases, used = _oracle_leg(d, mix, n_pi, cores)
-    except Exception as e:  # the baseline is informative; never fail the bench for it
-        return {"error": str(e)[:300]}
-    out = {
-        "value": 1.0 / dt, "unit": "proofs/sec", "cores": int(used), "kind": "port",
-        "sample": f"1 full proof of synth(d={d},{mix}) = 2^{d + 3} LDE rows (the benchmarked circuit, unscaled) in {dt:.2f} s on "
-                  f"{used} OpenMP threads = the CPU quota of this box ({os.cpu_count()} hardware threads visible; {cpu}); oracle/ C "
-                  f"restatement, not upstream plonky2 (no AVX2 field/Keccak kernels)",
-        "seconds": dt,
-        "phase_seconds": phases,
-    }
-    if single_thread_bits:
-        ds = min(17 if single_thread_bits < 0 else single_thread_bits, d)
-        try:
-            t1, ph1, _ = _oracle_leg(ds, mix, n_pi if ds == d else 0, 1, timeout=900)
-            scale = 1 << (d - ds)
-            out["single_thread"] = {"seconds": t1 * scale, "proofs_per_sec": 1.0 / (t1 * scale), "cores": 1, "phase_seconds": ph1,
-                                    "sample": (f"1 full proof of synth(d={ds},{mix}) = 2^{ds + 3} LDE rows, OMP_NUM_THREADS=1" +
-                                               ("" if scale == 1 else f", x{scale} (linear in rows; ignores the NTT log factor, which favours the CPU)")),
-                                    "scaled": scale != 1, "parallel_speedup": (t1 * scale) / dt}
-        except Exception as e:
-            out["single_thread"] = {"error": str(e)[:200]}
-    return out
 
 
 def _free_port():

@@ -351,7 +351,8 @@ static int circuit_create_one(const uint8_t *blob, size_t len, int device, p2gpu
       auto cost_main = [&](const GateDesc &g) { return gate_half_slot(g) ? 8u : cost(g); };
       uint32_t rest = 0;
       for (auto &g : c->gates) rest += cost_main(g);
-      c->gate_groups_half = rest > 2 * perm_cost ? 4u : 1u;
+      const char *gge = getenv("P2GPU_GATE_GROUPS_HALF");  // balance experiments only
+      c->gate_groups_half = gge ? (atoi(gge) == 4 ? 4u : 1u) : (rest > 2 * perm_cost ? 4u : 1u);
       uint32_t lm[4] = {perm_cost, 0, 0, 0}, ls[4] = {0, 0, 0, 0};
       const char *sge = getenv("P2GPU_SUMS_GROUPS");  // balance experiments only
       c->sums_groups = sge ? (atoi(sge) == 4 ? 4u : 1u) : (c->half_slots >= 2 ? 4u : 1u);

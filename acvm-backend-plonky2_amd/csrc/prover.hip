@@ -1146,7 +1146,9 @@ struct HostScan {
 };
 static void host_scan_suffix(const uint64_t *wires, uint32_t W, size_t n, uint32_t row, uint32_t lo, HostScan *out) {
   // several proofs may be in flight, each with its own scan: a quarter of the CPUs this process may use (the cgroup
-  // quota where there is one: the MI355X boxes show 256 hardware threads and grant 16 CPUs), at most 8
+  // quota where there is one: the MI355X boxes show 256 hardware threads and grant 16 CPUs), at most 8.  (Round 6 tried
+  // twice as many for a scan that finds no other one running: the 154 MB it reads at 2^17 rows take 1.8 ms either way --
+  // memory-bound -- and the extra threads cost the pageable upload's staging copy 0.5 ms; gpurun_out/r06_host.)
   static const unsigned T = [] {
     unsigned n = std::thread::hardware_concurrency();
     if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -1221,6 +1223,7 @@ static int prove_host(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, c
   // full matrix given: look for the unused-wire suffix on the host while the first chunks upload (see host_scan_suffix).
   // Only where it can pay: the handle still classifies columns (a handle that found a dense witness stopped), and the
   // witness of a sharded proof is split by columns anyway.
+  g_hp.mark("host:begin");
   HostScan scan;
   std::thread scan_thread;
   bool scanning = false;
@@ -1301,7 +1304,9 @@ static int prove_host(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, c
     if (scanning && col0 + chunk > c->R) {
       // the first chunk that reaches beyond the routed wires: the host scan decides what is left to upload.  Columns
       // already enqueued stay as they are (ncols never drops below col0)
+      g_hp.mark("host:enq");
       scan_thread.join();
+      g_hp.mark("host:WAIT(scan)");
       scanning = false;
       if (scan.ncols < W) {
         ncols = std::max(scan.ncols, col0);
@@ -1324,7 +1329,9 @@ static int prove_host(p2gpu_circuit *c, const uint64_t *wires, uint32_t ncols, c
     gl_t *vals = c->wires_vals.p + (size_t)col0 * n;
     const uint32_t nh = col0 < ncols ? std::min(nc, ncols - col0) : 0;  // columns of this chunk that come from the host
     if (nh) {
+      g_hp.mark("host:enq");
       HIP_TRY(hipMemcpyAsync(vals, wires + (size_t)col0 * n, 8 * (size_t)nh * n, hipMemcpyHostToDevice, c->copy_stream));
+      g_hp.mark("host:h2d");
       HIP_TRY(hipEventRecord(c->copy_events[ci], c->copy_stream));
       HIP_TRY(hipStreamWaitEvent(c->stream, c->copy_events[ci], 0));
     }

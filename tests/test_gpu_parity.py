@@ -167,6 +167,43 @@ for d, mix in ((8, "sha"), (11, "sha"), (14, "ecdsa")):
     assert len(outs[0]) == 16 and outs[0] == outs[1] == outs[2] == outs[3]
 
 
+def test_measurement_switches_keep_every_byte(pkg, orc, gpu):
+    """Every other environment switch of INTEGRATION.md section 7 (the host-witness pipeline's, the gate-group balance, the staged /
+    unstaged gate sums, the round-4 column groups), each in a process of its own: the proofs of a `sha` circuit through the
+    host-matrix entry and of an `ecdsa` circuit with the half-domain route forced are the ORACLE's bytes under every one of them."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    want = []
+    for d, mix in ((11, "sha"), (12, "ecdsa")):
+        blob, wires = pkg.make_circuit(d, mix, 9)
+        want.append("PROOF %d %s %s" % (d, mix, hashlib.sha256(orc.OracleCircuit(blob).prove(wires)[0]).hexdigest()))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, {root!r})
+import __graft_entry__ as ge
+pkg = ge.load_package()
+for d, mix in ((11, "sha"), (12, "ecdsa")):
+    blob, wires = pkg.make_circuit(d, mix, 9)
+    cd = pkg.CircuitData(blob)
+    cd.set("half_gates", 2)
+    host = cd.prove(wires).to_bytes()                                                  # p2gpu_prove: chunked upload, host scan
+    assert cd.prove(torch.from_numpy(wires.view(np.int64)).cuda()).to_bytes() == host  # p2gpu_prove_dev
+    print("PROOF", d, mix, hashlib.sha256(host).hexdigest())
+""".format(root=root)
+    envs = ({}, {"P2GPU_CHUNK_BLOCKS": "1"}, {"P2GPU_CHUNK_BLOCKS": "5"}, {"P2GPU_HOST_PRESCAN": "0"}, {"P2GPU_HALF_GATES": "0"},
+            {"P2GPU_SUMS_STAGE": "0"}, {"P2GPU_GATE_GROUPS": "4", "P2GPU_GATE_GROUPS_HALF": "4", "P2GPU_SUMS_GROUPS": "4"},
+            {"P2GPU_GATE_GROUPS": "1", "P2GPU_GATE_GROUPS_HALF": "1", "P2GPU_SUMS_GROUPS": "1"}, {"P2GPU_PERM_COST": "100000"},
+            {"P2GPU_PERM_COST": "1", "P2GPU_GATE_GROUPS": "4", "P2GPU_GATE_GROUPS_HALF": "4"}, {"P2GPU_NTT_GROUP_MB": "1"})
+    for env in envs:
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (env, r.stderr[-2000:])
+        assert [ln for ln in r.stdout.splitlines() if ln.startswith("PROOF")] == want, env
+
+
 @pytest.mark.parametrize("d", [21, 22])
 def test_deep_transforms(pkg, orc, gpu, d):
     """2^21 points: 12 + 9 layers (one strided pass with 64-byte runs); 2^22: 12 + 5 + 5 (two strided
